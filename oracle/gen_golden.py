@@ -1,0 +1,226 @@
+"""
+Golden-vector generator -- TEST INFRASTRUCTURE, runs ONLY in the build container.
+
+Imports the unmodified reference from /root/reference (PYTHONPATH is set here, the
+reference is never copied or shipped), feeds it this build's own seeded synthetic
+inputs (oracle.tfr_oracle.synth_chirp) and writes inputs + reference outputs as
+small .npz fixtures under tests/golden/.  The GPU box only ever sees the .npz files.
+
+    python oracle/gen_golden.py            # small + medium fixtures (~1 min)
+    python oracle/gen_golden.py --large    # adds n = 2^16 and the config-2 size n = 2^20 (~4 min, ~10 GB RSS)
+"""
+import argparse
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import scipy  # noqa: E402
+from quantum_inferno import cwt_atoms, scales_dyadic, styx_cwt, styx_fft, styx_stx, tfr_info  # noqa: E402
+from quantum_inferno.utilities import calculations, rescaling  # noqa: E402
+
+from oracle.tfr_oracle import synth_chirp  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+VERSIONS = np.array([np.__version__, scipy.__version__, "quantum-inferno 1.1.3"])
+
+
+def quiet(fn, *a, **k):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, versions=VERSIONS, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(arrays)} arrays")
+
+
+def gen_bands():
+    d = {}
+    # the reference's own (commented-out) known-answer test, tests/test_scales_dyadic.py:8-21
+    d["kat_100hz_8192_n6"] = scales_dyadic.log_frequency_hz_from_fft_points(100.0, 8192, 6, 1.0, scales_dyadic.Slice.G3)
+    combos = []
+    for fs in (80.0, 800.0, 1000.0, 8000.0, 48000.0):
+        for log2n in (8, 10, 13, 16, 20):
+            for order in (1, 3, 6, 12, 24):
+                n = 2 ** log2n
+                f = scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
+                if len(f) == 0:
+                    continue
+                key = f"fs{int(fs)}_n{log2n}_o{order}"
+                combos.append(key)
+                d[f"f_{key}"] = f
+                freq = np.fft.fftfreq(n, 1 / fs)
+                d[f"idx_{key}"] = np.array([np.abs(freq - fj).argmin() for fj in f], dtype=np.int64)
+                s, w = scales_dyadic.scale_from_frequency_hz(order, f, fs)
+                d[f"scale_{key}"] = s
+                # cwt_atoms band table (cwt_chirp_from_sig's call chain)
+                _, fmin = cwt_atoms.chirp_scales_from_duration(order, n / fs, 0.0, scales_dyadic.Slice.G2)
+                out = quiet(
+                    cwt_atoms.chirp_frequency_bands,
+                    scale_order_input=order,
+                    frequency_low_input=fmin,
+                    frequency_sample_rate_input=fs,
+                    frequency_high_input=fs / 2.0,
+                )
+                d[f"chirpf_{key}"] = np.flip(out[4])
+                d[f"chirpmq_{key}"] = np.array(out[:4], dtype=np.float64)
+    d["combos"] = np.array(combos)
+    # STFT segment sizing (styx_fft.py:31-41) and rounding helpers
+    seg = []
+    for fs in (80.0, 800.0, 1000.0, 8000.0, 48000.0):
+        for order in (1, 3, 6, 12, 24):
+            dur = scales_dyadic.cycles_from_order(order) / (fs * 0.075 / 4)
+            seg.append((fs, order, 2 ** calculations.get_num_points(fs, dur, "ceil", "log2")))
+    d["stft_seg"] = np.array(seg, dtype=np.float64)
+    d["cycles"] = np.array([scales_dyadic.cycles_from_order(o) for o in (0.5, 0.75, 1, 3, 6, 12, 24)])
+    d["mqg"] = np.array([cwt_atoms.chirp_mqg_from_n(o) for o in (1, 3, 6, 12, 24)])
+    d["log2eps_pm100"] = np.array([rescaling.to_log2_with_epsilon(100.0), rescaling.to_log2_with_epsilon(-100.0)])
+    save("bands.npz", **d)
+
+
+def gen_small():
+    """n = 1024: full panels."""
+    d = {}
+    n = 1024
+    for order, fs in ((3, 1000.0), (12, 800.0)):
+        key = f"o{order}_fs{int(fs)}"
+        sig = synth_chirp(n, fs, dtype=np.float64)
+        d[f"sig_{key}"] = sig
+        for dt in ("norm", "spect") if order == 3 else ("norm",):
+            f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs, dictionary_type=dt)
+            d[f"cwt_{dt}_{key}"] = cwt
+        d[f"f_{key}"] = f
+        d[f"t_{key}"] = t
+        atoms, t_c, scale, omega, amp = styx_cwt.wavelet_centered_4cwt(order, n, f, fs, "norm")
+        d[f"atoms_{key}"] = atoms[[0, len(f) // 2, len(f) - 1]]
+        d[f"atom_scale_{key}"] = scale[:, 0]
+        d[f"atom_amp_{key}"] = amp[:, 0]
+        f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
+        assert np.array_equal(f, f2)
+        d[f"stx_{key}"] = stx
+        c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order)
+        d[f"chirp_cwt_{key}"] = c
+        d[f"chirp_bits_{key}"] = bits
+        d[f"chirp_f_{key}"] = fc
+        if order == 3:
+            c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order, dictionary_type="spect")
+            d[f"chirp_cwt_spect_{key}"] = c
+            c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order, cwt_type="conv")
+            d[f"chirp_cwt_conv_{key}"] = c
+    # tfr_info on the order-3 CWT power panel (tutorial convention power = 2|z|^2, s04_tone_tfr.py:92)
+    p = 2 * np.abs(d["cwt_norm_o3_fs1000"]) ** 2
+    d["info_power"] = p
+    a, b, c = tfr_info.power_dynamics_scaled_bits(p)
+    d["info_bits"], d["info_bits_time"], d["info_bits_freq"] = a, b, c
+    for nm, obj in (
+        ("tot", tfr_info.shannon_stft_from_tfr_power(p)),
+        ("time", tfr_info.ShannonStftPerTime(p)),
+        ("freq", tfr_info.ShannonStftPerFreq(p)),
+    ):
+        d[f"sh_{nm}_info"] = obj.info
+        d[f"sh_{nm}_bits"] = obj.shannon_bits
+        d[f"sh_{nm}_ref"] = np.array(obj.ref_bits)
+        d[f"sh_{nm}_isnr"] = obj.isnr
+        d[f"sh_{nm}_esnr"] = obj.esnr
+    tdr, fftc = tfr_info.shannon_tdr_fft(d["sig_o3_fs1000"])
+    for nm, obj in (("tdr", tdr), ("fft", fftc)):
+        d[f"sh1_{nm}_info"], d[f"sh1_{nm}_entropy"] = obj.info, obj.entropy
+        d[f"sh1_{nm}_isnr"], d[f"sh1_{nm}_esnr"] = obj.isnr, obj.esnr
+        d[f"sh1_{nm}_ref"] = np.array(obj.ref_entropy)
+    save("small_n1024.npz", **d)
+
+
+def gen_stft():
+    d = {}
+    for log2n, fs in ((13, 1000.0), (13, 800.0), (16, 1000.0)):
+        n = 2 ** log2n
+        for dtype in (np.float64, np.float32):
+            sig = synth_chirp(n, fs, dtype=dtype)
+            tag = f"n{log2n}_fs{int(fs)}_{np.dtype(dtype).name}"
+            d[f"sig_{tag}"] = sig
+            for order in (3, 12):
+                z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
+                cols = slice(None) if (log2n == 13 or (order == 3 and dtype == np.float64)) else slice(0, None, 8)
+                d[f"z_{tag}_o{order}"] = z[:, cols]
+                d[f"bits_{tag}_o{order}"] = bits[:, cols].astype(np.float32) if log2n == 16 else bits[:, cols]
+                d[f"t_{tag}_o{order}"] = t
+                d[f"f_{tag}_o{order}"] = f
+                d[f"shape_{tag}_o{order}"] = np.array(z.shape)
+    # stft_complex_pow2 with its own default alpha = 0.25 Tukey, 2-D input (axis -1)
+    sig2 = np.stack([synth_chirp(4096, 1000.0, c, 3, np.float64) for c in range(3)])
+    f, t, z = styx_fft.stft_complex_pow2(sig2, 1000.0, 256)
+    d["sig_2d"], d["z_2d_alpha025"], d["t_2d"], d["f_2d"] = sig2, z, t, f
+    save("stft.npz", **d)
+
+
+def panel_digest(panel, rows):
+    p = np.abs(panel) ** 2
+    sh = tfr_info.shannon_stft_from_tfr_power(p)
+    n = panel.shape[1]
+    tsel = np.unique(np.concatenate([np.arange(0, n, max(1, n // 512)), np.arange(n // 2 - 256, n // 2 + 256)]))
+    return {
+        "rows": panel[rows][:, tsel] if n > 8192 else panel[rows],
+        "tsel": tsel,
+        "psum_band": p.sum(axis=1),
+        "psum_time": p.sum(axis=0)[tsel] if n > 8192 else p.sum(axis=0),
+        "pmax": np.array(p.max()),
+        "ptot": np.array(p.sum()),
+        "entropy_bits": np.array(np.sum(sh.shannon_bits)),
+    }
+
+
+def gen_sized(log2n, orders, fs, name):
+    d = {}
+    n = 2 ** log2n
+    sig = synth_chirp(n, fs, dtype=np.float32)
+    if n <= 65536:
+        d["sig"] = sig
+    else:  # regenerated by the tests with the same seeded generator; pinned by samples
+        d["sig_samples"] = sig[:: n // 4096]
+    for order in orders:
+        f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
+        rows = np.array([0, len(f) // 2, len(f) - 1])
+        d[f"f_o{order}"], d[f"rows_o{order}"] = f, rows
+        for k, v in panel_digest(cwt, rows).items():
+            d[f"cwt_{k}_o{order}"] = v
+        del cwt
+        f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
+        for k, v in panel_digest(stx, rows).items():
+            d[f"stx_{k}_o{order}"] = v
+        del stx
+        c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order)
+        rows_c = np.array([0, len(fc) // 2, len(fc) - 1])
+        d[f"chirp_f_o{order}"], d[f"chirp_rowsel_o{order}"] = fc, rows_c
+        for k, v in panel_digest(c, rows_c).items():
+            d[f"chirp_{k}_o{order}"] = v
+        del c, bits
+        print(f"  n=2^{log2n} order {order} done", flush=True)
+    save(name, **d)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--large", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "medium"] + (["large"] if a.large else [])
+    if "bands" in todo:
+        gen_bands()
+    if "small" in todo:
+        gen_small()
+    if "stft" in todo:
+        gen_stft()
+    if "medium" in todo:
+        gen_sized(13, (3, 12), 1000.0, "medium_n8192.npz")
+    if "large" in todo:
+        gen_sized(16, (3, 12), 800.0, "large_n65536.npz")
+        gen_sized(20, (3,), 1000.0, "large_n1048576.npz")

@@ -1,0 +1,65 @@
+"""Builds libqi_tfr.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+The library is linked against the HIP runtime and hipFFT that PyTorch-ROCm ships
+(torch/lib), not the copies under /opt/rocm/lib: device pointers and streams cross the
+C ABI from torch, so both sides must share ONE HIP runtime in the process.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libqi_tfr.so")
+SOURCES = ["qi_api.hip", "qi_kernels.hip"]
+ARCH = "gfx950"
+
+
+def torch_lib_dir():
+    import importlib.util
+
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        raise RuntimeError("PyTorch-ROCm is required (its bundled HIP runtime is the one the library links)")
+    return os.path.join(list(spec.submodule_search_locations)[0], "lib")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "qi_tfr.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    tlib = torch_lib_dir()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, "-c", "-fPIC", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
+               "-I", CSRC, "-Wall", "-Wno-unused-function", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    link = ["g++", "-shared", "-o", LIB, *objs, f"-L{tlib}", "-lamdhip64", "-lhipfft", f"-Wl,-rpath,{tlib}",
+            "-Wl,--no-undefined", "-lpthread"]
+    if verbose:
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

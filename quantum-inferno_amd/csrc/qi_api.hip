@@ -1,0 +1,562 @@
+// C ABI of libqi_tfr.so: plans, tiling over (channel, band) tiles, the hipFFT engine.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <tuple>
+#include <vector>
+
+#include "qi_common.hpp"
+
+namespace qi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// ---- hipFFT plan cache (one per qi_plan, plus a process-wide one for the plan-less STFT entry) ----
+struct FftCache {
+  using Key = std::tuple<int, int64_t, int64_t>;  // hipfftType, length, batch
+  std::map<Key, hipfftHandle> plans;
+  void* work = nullptr;
+  size_t work_bytes = 0;
+
+  int get(hipfftType type, int64_t len, int64_t batch, hipfftHandle* out) {
+    Key k{(int)type, len, batch};
+    auto it = plans.find(k);
+    if (it != plans.end()) {
+      *out = it->second;
+      return QI_OK;
+    }
+    QI_REQUIRE(len > 0 && len < (1ll << 31) && batch > 0 && batch < (1ll << 31), "fft size out of range");
+    hipfftHandle h;
+    QI_FFT(hipfftCreate(&h));
+    QI_FFT(hipfftSetAutoAllocation(h, 0));
+    int nn[1] = {(int)len};
+    size_t ws = 0;
+    QI_FFT(hipfftMakePlanMany(h, 1, nn, nullptr, 1, (int)len, nullptr, 1, (int)len, type, (int)batch, &ws));
+    if (ws > work_bytes) {
+      // growing the shared work area happens while a plan warms up, never in steady state
+      QI_HIP(hipDeviceSynchronize());
+      if (work) QI_HIP(hipFree(work));
+      work = nullptr;
+      work_bytes = 0;
+      QI_HIP(hipMalloc(&work, ws));
+      work_bytes = ws;
+      for (auto& kv : plans) QI_FFT(hipfftSetWorkArea(kv.second, work));
+    }
+    if (work) QI_FFT(hipfftSetWorkArea(h, work));
+    plans[k] = h;
+    *out = h;
+    return QI_OK;
+  }
+  void clear() {
+    for (auto& kv : plans) hipfftDestroy(kv.second);
+    plans.clear();
+    if (work) (void)hipFree(work);
+    work = nullptr;
+    work_bytes = 0;
+  }
+};
+
+template <typename T>
+int fft_c2c(FftCache& fc, cplx<T>* data, int64_t len, int64_t batch, int dir, hipStream_t st);
+template <>
+int fft_c2c<float>(FftCache& fc, float2* data, int64_t len, int64_t batch, int dir, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_C2C, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecC2C(h, (hipfftComplex*)data, (hipfftComplex*)data, dir));
+  return QI_OK;
+}
+template <>
+int fft_c2c<double>(FftCache& fc, double2* data, int64_t len, int64_t batch, int dir, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_Z2Z, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecZ2Z(h, (hipfftDoubleComplex*)data, (hipfftDoubleComplex*)data, dir));
+  return QI_OK;
+}
+template <typename T>
+int fft_r2c(FftCache& fc, T* in, cplx<T>* out, int64_t len, int64_t batch, hipStream_t st);
+template <>
+int fft_r2c<float>(FftCache& fc, float* in, float2* out, int64_t len, int64_t batch, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_R2C, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecR2C(h, in, (hipfftComplex*)out));
+  return QI_OK;
+}
+template <>
+int fft_r2c<double>(FftCache& fc, double* in, double2* out, int64_t len, int64_t batch, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_D2Z, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecD2Z(h, in, (hipfftDoubleComplex*)out));
+  return QI_OK;
+}
+
+static std::mutex g_stft_mu;
+static std::map<int, FftCache> g_stft_fft;  // per device
+
+}  // namespace qi
+
+using namespace qi;
+
+struct qi_plan {
+  qi_plan_desc d{};
+  int64_t n = 0;
+  int64_t L = 0;  // zero-padded length of the linear (styx_cwt) correlation
+  void* bank[2] = {nullptr, nullptr};
+  int32_t nb[2] = {0, 0};
+  int64_t* d_stx_idx = nullptr;
+  double* d_stx_coef = nullptr;
+  int32_t nb_stx = 0;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  FftCache fft;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Tile {
+  int64_t Ct, Bt, ntb, nblk;
+  size_t off_x, off_y, off_pb, off_ps;
+};
+
+// Split the plan's scratch into X [Ct][L], Y [Ct][Bt][L] and the reduction partials.
+template <typename T>
+int plan_tiles(const qi_plan* p, int64_t C, int64_t B, int64_t L, Tile* t) {
+  const size_t row = (size_t)L * sizeof(cplx<T>);
+  const int64_t nblk = ceil_div(p->n, kEpiSpan);
+  const size_t part = align_up((size_t)B * nblk * 8) + align_up((size_t)B * nblk * 24);  // per channel, ntb <= B
+  const size_t per_chan_full = row * (size_t)(B + 1) + part + 2048;
+  int64_t Ct, Bt;
+  if (per_chan_full <= p->ws_bytes) {
+    Bt = B;
+    Ct = (int64_t)(p->ws_bytes / per_chan_full);
+    if (Ct > C) Ct = C;
+  } else {
+    Ct = 1;
+    if (p->ws_bytes < part + 2 * row + 2048) {
+      set_error("workspace of %zu bytes cannot hold one (channel, band) tile of %zu bytes", p->ws_bytes,
+                part + 2 * row + 2048);
+      return QI_ERR_NOMEM;
+    }
+    Bt = (int64_t)((p->ws_bytes - part - 2048) / row) - 1;
+    if (Bt > B) Bt = B;
+  }
+  t->Ct = Ct;
+  t->Bt = Bt;
+  t->ntb = ceil_div(B, Bt);
+  t->nblk = nblk;
+  size_t o = 0;
+  t->off_x = o;
+  o += align_up(row * (size_t)Ct);
+  t->off_y = o;
+  o += align_up(row * (size_t)Ct * (size_t)Bt);
+  t->off_pb = o;
+  o += align_up((size_t)Ct * B * nblk * 8);
+  t->off_ps = o;
+  return QI_OK;
+}
+
+enum class Kind { Linear, Circular, Stockwell };
+
+template <typename T>
+int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
+  const int64_t n = p->n;
+  const T* sig = static_cast<const T*>(sig_v);
+  int64_t L, B, off;
+  const cplx<T>* H = nullptr;
+  if (kind == Kind::Linear) {
+    L = p->L;
+    B = p->nb[QI_BANK_STYX];
+    off = (n - 1) / 2;
+    H = static_cast<const cplx<T>*>(p->bank[QI_BANK_STYX]);
+  } else if (kind == Kind::Circular) {
+    L = n;
+    B = p->nb[QI_BANK_ATOMS];
+    off = n / 2;
+    H = static_cast<const cplx<T>*>(p->bank[QI_BANK_ATOMS]);
+  } else {
+    L = n;
+    B = p->nb_stx;
+    off = 0;
+  }
+  if (B <= 0) {
+    set_error("plan has no band table for this transform");
+    return QI_ERR_STATE;
+  }
+  Tile tl;
+  QI_TRY(plan_tiles<T>(p, C, B, L, &tl));
+  cplx<T>* X = reinterpret_cast<cplx<T>*>(p->ws + tl.off_x);
+  cplx<T>* Y = reinterpret_cast<cplx<T>*>(p->ws + tl.off_y);
+  double* part_band = reinterpret_cast<double*>(p->ws + tl.off_pb);
+  double* part_stat = reinterpret_cast<double*>(p->ws + tl.off_ps);
+  const bool want_band = out->power_band != nullptr;
+  const bool want_stat = out->stats != nullptr;
+
+  for (int64_t c0 = 0; c0 < C; c0 += tl.Ct) {
+    const int64_t ct = (C - c0 < tl.Ct) ? C - c0 : tl.Ct;
+    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, L, st));
+    QI_TRY(fft_c2c<T>(p->fft, X, L, ct, HIPFFT_FORWARD, st));
+    int64_t tb = 0;
+    for (int64_t j0 = 0; j0 < B; j0 += tl.Bt, ++tb) {
+      const int64_t bt = (B - j0 < tl.Bt) ? B - j0 : tl.Bt;
+      if (kind == Kind::Stockwell)
+        QI_TRY(launch_stx_window<T>(X, Y, ct, bt, n, p->d_stx_idx + j0, p->d_stx_coef + j0, st));
+      else
+        QI_TRY(launch_mul_bank<T>(X, H + j0 * L, Y, ct, bt, L, st));
+      QI_TRY(fft_c2c<T>(p->fft, Y, L, ct * bt, HIPFFT_BACKWARD, st));
+      EpiArgs<T> a{};
+      a.Y = Y;
+      a.L = L;
+      a.n = n;
+      a.off = off;
+      a.Ct = ct;
+      a.Bt = bt;
+      a.B = B;
+      a.j0 = j0;
+      a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      a.power_time = out->power_time ? static_cast<T*>(out->power_time) + c0 * n : nullptr;
+      a.part_band = want_band ? part_band : nullptr;
+      a.part_stat = want_stat ? part_stat : nullptr;
+      a.tile_b = tb;
+      a.ntile_b = tl.ntb;
+      a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      QI_TRY(launch_epilogue<T>(a, st));
+    }
+    if (want_band || want_stat)
+      QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
+                             want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
+                             want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, tl.nblk,
+                             tl.ntb * tl.nblk, st));
+  }
+  return QI_OK;
+}
+
+template <typename T>
+int build_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipStream_t st) {
+  const int64_t n = p->n;
+  const int circular = bank == QI_BANK_ATOMS;
+  const int64_t L = circular ? n : p->L;
+  const size_t row64 = (size_t)L * sizeof(double2);
+  int64_t chunk = (int64_t)(p->ws_bytes / row64);
+  if (chunk < 1) {
+    set_error("workspace too small to build one bank row (%zu bytes needed)", row64);
+    return QI_ERR_NOMEM;
+  }
+  if (chunk > B) chunk = B;
+  double2* rows = reinterpret_cast<double2*>(p->ws);
+  cplx<T>* dst = static_cast<cplx<T>*>(p->bank[bank]);
+  for (int32_t j0 = 0; j0 < B; j0 += (int32_t)chunk) {
+    const int nbk = (B - j0 < chunk) ? B - j0 : (int)chunk;
+    QI_TRY(launch_bank_rows(rows, n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0, nbk, st));
+    QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
+    QI_TRY(launch_bank_convert<T>(rows, dst + (int64_t)j0 * L, (int64_t)nbk * L, circular, 1.0 / (double)L, st));
+  }
+  return QI_OK;
+}
+
+template <typename T>
+int stft_impl(int device, const void* sig, int64_t C, int64_t n, const void* window, int64_t seg, int64_t hop,
+                     int64_t nfft, double scale, void* Z, void* bits, double eps, char* scratch, hipStream_t st) {
+  const int64_t nseg = qi_stft_segments(n, seg, hop);
+  const int64_t nf = nfft / 2 + 1;
+  T* frames = reinterpret_cast<T*>(scratch);
+  cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
+  QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
+                               nfft, nseg, st));
+  {
+    std::lock_guard<std::mutex> lk(g_stft_mu);
+    QI_TRY(fft_r2c<T>(g_stft_fft[device], frames, F, nfft, C * nseg, st));
+  }
+  return launch_stft_transpose<T>(F, static_cast<cplx<T>*>(Z), static_cast<T*>(bits), C, nseg, nf, (T)scale,
+                                  (T)(eps == 0.0 ? 2.220446049250313e-16 : eps), st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qi_abi_version(void) { return QI_TFR_ABI_VERSION; }
+const char* qi_last_error(void) { return g_err; }
+
+int qi_device_info(int device, char* name, size_t name_len, int64_t* hbm_bytes, int32_t* compute_units) {
+  hipDeviceProp_t prop;
+  QI_HIP(hipGetDeviceProperties(&prop, device));
+  if (name && name_len) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return QI_OK;
+}
+
+int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
+  QI_REQUIRE(plan && desc, "null plan/desc");
+  *plan = nullptr;
+  QI_REQUIRE(desc->n >= 2 && desc->n <= (1ll << 28), "n = %lld out of range", (long long)desc->n);
+  QI_REQUIRE(desc->dtype == QI_F32 || desc->dtype == QI_F64, "bad dtype %d", desc->dtype);
+  QI_REQUIRE(desc->engine >= QI_ENGINE_AUTO && desc->engine <= QI_ENGINE_NATIVE, "bad engine %d", desc->engine);
+  if (desc->engine == QI_ENGINE_NATIVE) {
+    set_error("native engine not available in this build");
+    return QI_ERR_UNSUPPORTED;
+  }
+  DeviceGuard g(desc->device);
+  if (!g.ok) {
+    set_error("hipSetDevice(%d) failed", desc->device);
+    return QI_ERR_HIP;
+  }
+  qi_plan* p = new (std::nothrow) qi_plan();
+  QI_REQUIRE(p, "out of host memory");
+  p->d = *desc;
+  p->n = desc->n;
+  // scipy.signal.fftconvolve pads to next_fast_len(2n-1) (= 2n when n = 2^k); any L >= 2n-1 gives the
+  // same linear correlation, so other n use the next power of two.
+  p->L = is_pow2(desc->n) ? 2 * desc->n : next_pow2(2 * desc->n - 1);
+  p->ws_bytes = desc->workspace_bytes > 0 ? (size_t)desc->workspace_bytes : ((size_t)2 << 30);
+  if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {
+    set_error("hipMalloc of %zu workspace bytes failed", p->ws_bytes);
+    delete p;
+    return QI_ERR_HIP;
+  }
+  *plan = p;
+  return QI_OK;
+}
+
+int qi_plan_destroy(qi_plan* p) {
+  if (!p) return QI_OK;
+  DeviceGuard g(p->d.device);
+  (void)hipDeviceSynchronize();
+  p->fft.clear();
+  for (int b = 0; b < 2; ++b)
+    if (p->bank[b]) (void)hipFree(p->bank[b]);
+  if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);
+  if (p->d_stx_coef) (void)hipFree(p->d_stx_coef);
+  if (p->ws) (void)hipFree(p->ws);
+  delete p;
+  return QI_OK;
+}
+
+int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, const double* p_im,
+                           const double* omega, const double* amp, qi_stream stream) {
+  QI_REQUIRE(p && p_re && p_im && omega && amp, "null argument");
+  QI_REQUIRE(bank == QI_BANK_STYX || bank == QI_BANK_ATOMS, "bad bank %d", bank);
+  QI_REQUIRE(B > 0 && B <= 65535, "band count %d out of range", B);
+  DeviceGuard g(p->d.device);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t L = bank == QI_BANK_ATOMS ? p->n : p->L;
+  const size_t esz = p->d.dtype == QI_F64 ? sizeof(double2) : sizeof(float2);
+  if (p->bank[bank]) {
+    QI_HIP(hipDeviceSynchronize());
+    QI_HIP(hipFree(p->bank[bank]));
+    p->bank[bank] = nullptr;
+    p->nb[bank] = 0;
+  }
+  QI_HIP(hipMalloc(&p->bank[bank], (size_t)B * L * esz));
+  double* d_par = nullptr;
+  QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
+  std::vector<double> host((size_t)4 * B);
+  memcpy(&host[0], p_re, B * sizeof(double));
+  memcpy(&host[B], p_im, B * sizeof(double));
+  memcpy(&host[2 * B], omega, B * sizeof(double));
+  memcpy(&host[3 * B], amp, B * sizeof(double));
+  int rc = QI_OK;
+  if (hipMemcpy(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy of band parameters failed");
+    rc = QI_ERR_HIP;
+  }
+  if (rc == QI_OK)
+    rc = p->d.dtype == QI_F64 ? build_bank<double>(p, bank, B, d_par, st) : build_bank<float>(p, bank, B, d_par, st);
+  if (rc == QI_OK && hipStreamSynchronize(st) != hipSuccess) {
+    set_error("bank build failed on the device: %s", hipGetErrorString(hipGetLastError()));
+    rc = QI_ERR_HIP;
+  }
+  (void)hipFree(d_par);
+  if (rc == QI_OK) p->nb[bank] = B;
+  return rc;
+}
+
+int qi_gabor_atoms(int device, int64_t n, int32_t B, const double* p_re, const double* p_im, const double* omega,
+                   const double* amp, void* out, qi_stream stream) {
+  QI_REQUIRE(p_re && p_im && omega && amp && out, "null argument");
+  QI_REQUIRE(n >= 2 && B > 0 && B <= 65535, "bad atom bank shape");
+  DeviceGuard g(device);
+  double* d_par = nullptr;
+  QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
+  std::vector<double> host((size_t)4 * B);
+  memcpy(&host[0], p_re, B * sizeof(double));
+  memcpy(&host[B], p_im, B * sizeof(double));
+  memcpy(&host[2 * B], omega, B * sizeof(double));
+  memcpy(&host[3 * B], amp, B * sizeof(double));
+  int rc = QI_OK;
+  if (hipMemcpy(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy of band parameters failed");
+    rc = QI_ERR_HIP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (rc == QI_OK)
+    rc = launch_bank_rows((double2*)out, n, n, 1, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, 0, B, st);
+  if (rc == QI_OK && hipStreamSynchronize(st) != hipSuccess) {
+    set_error("atom kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = QI_ERR_HIP;
+  }
+  (void)hipFree(d_par);
+  return rc;
+}
+
+int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, const double* sigma) {
+  QI_REQUIRE(p && shift_index && sigma, "null argument");
+  QI_REQUIRE(B > 0 && B <= 65535, "band count %d out of range", B);
+  for (int32_t j = 0; j < B; ++j)
+    QI_REQUIRE(shift_index[j] >= 0 && shift_index[j] < p->n, "shift_index[%d] = %lld outside [0, n)", j,
+               (long long)shift_index[j]);
+  DeviceGuard g(p->d.device);
+  if (p->d_stx_idx) {
+    QI_HIP(hipDeviceSynchronize());
+    QI_HIP(hipFree(p->d_stx_idx));
+    QI_HIP(hipFree(p->d_stx_coef));
+    p->d_stx_idx = nullptr;
+    p->d_stx_coef = nullptr;
+    p->nb_stx = 0;
+  }
+  std::vector<double> coef(B);
+  const double k = 2.0 * M_PI / (double)p->n * std::sqrt(0.5 * M_LOG2E);
+  for (int32_t j = 0; j < B; ++j) coef[j] = sigma[j] * k;
+  QI_HIP(hipMalloc((void**)&p->d_stx_idx, B * sizeof(int64_t)));
+  QI_HIP(hipMalloc((void**)&p->d_stx_coef, B * sizeof(double)));
+  QI_HIP(hipMemcpy(p->d_stx_idx, shift_index, B * sizeof(int64_t), hipMemcpyHostToDevice));
+  QI_HIP(hipMemcpy(p->d_stx_coef, coef.data(), B * sizeof(double), hipMemcpyHostToDevice));
+  p->nb_stx = B;
+  return QI_OK;
+}
+
+int64_t qi_plan_bands(const qi_plan* p, int which) {
+  if (!p) return 0;
+  if (which == QI_BANK_STYX || which == QI_BANK_ATOMS) return p->nb[which];
+  return which == 2 ? p->nb_stx : 0;
+}
+
+int qi_cwt(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* out, qi_stream stream) {
+  QI_REQUIRE(p && sig && out, "null argument");
+  QI_REQUIRE(bank == QI_BANK_STYX || bank == QI_BANK_ATOMS, "bad bank %d", bank);
+  QI_REQUIRE(C > 0, "n_channels must be positive");
+  DeviceGuard g(p->d.device);
+  const Kind k = bank == QI_BANK_STYX ? Kind::Linear : Kind::Circular;
+  return p->d.dtype == QI_F64 ? run_transform<double>(p, k, sig, C, out, (hipStream_t)stream)
+                              : run_transform<float>(p, k, sig, C, out, (hipStream_t)stream);
+}
+
+int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_stream stream) {
+  QI_REQUIRE(p && sig && out, "null argument");
+  QI_REQUIRE(C > 0, "n_channels must be positive");
+  DeviceGuard g(p->d.device);
+  return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
+                              : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
+}
+
+// ---- STFT ----------------------------------------------------------------------------------------
+int64_t qi_stft_segments(int64_t n, int64_t seg, int64_t hop) {
+  if (n <= 0 || seg <= 0 || hop <= 0 || hop > seg) return 0;
+  const int64_t len0 = n + 2 * (seg / 2);  // boundary='zeros' extends by seg//2 on both sides
+  const int64_t nadd = ((hop - ((len0 - seg) % hop)) % hop) % seg;  // padded=True
+  return (len0 + nadd - seg) / hop + 1;
+}
+
+int64_t qi_stft_scratch_bytes(int dtype, int64_t C, int64_t n, int64_t seg, int64_t hop, int64_t nfft) {
+  const int64_t nseg = qi_stft_segments(n, seg, hop);
+  const size_t e = dtype == QI_F64 ? 8 : 4;
+  return (int64_t)(align_up((size_t)C * nseg * nfft * e) + align_up((size_t)C * nseg * (nfft / 2 + 1) * 2 * e));
+}
+
+int qi_stft(int dtype, int device, const void* sig, int64_t C, int64_t n, const void* window, int64_t seg,
+            int64_t hop, int64_t nfft, double scale, void* Z, void* bits, double eps, void* scratch,
+            int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(sig && window && Z && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && n > 0 && seg > 0 && hop > 0 && hop <= seg && nfft >= seg, "bad STFT geometry");
+  QI_REQUIRE(scratch_bytes >= qi_stft_scratch_bytes(dtype, C, n, seg, hop, nfft), "scratch too small");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? stft_impl<double>(device, sig, C, n, window, seg, hop, nfft, scale, Z, bits, eps,
+                                             (char*)scratch, (hipStream_t)stream)
+                         : stft_impl<float>(device, sig, C, n, window, seg, hop, nfft, scale, Z, bits, eps,
+                                            (char*)scratch, (hipStream_t)stream);
+}
+
+// ---- tfr_info -------------------------------------------------------------------------------------
+int64_t qi_power_marginals_scratch_bytes(int64_t C, int64_t B, int64_t n) {
+  const int64_t nblk = ceil_div(n, kEpiSpan);
+  return (int64_t)(align_up((size_t)C * B * nblk * 8) + align_up((size_t)C * nblk * 24));
+}
+
+int qi_power_marginals(int dtype, int device, const void* power, int64_t C, int64_t B, int64_t n, void* power_band,
+                       void* power_time, void* stats, void* scratch, int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(power && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && B > 0 && n > 0, "bad panel shape");
+  QI_REQUIRE(scratch_bytes >= qi_power_marginals_scratch_bytes(C, B, n), "scratch too small");
+  DeviceGuard g(device);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = ceil_div(n, kEpiSpan);
+  double* pb = reinterpret_cast<double*>(scratch);
+  double* ps = reinterpret_cast<double*>((char*)scratch + align_up((size_t)C * B * nblk * 8));
+  if (dtype == QI_F64)
+    QI_TRY(launch_power_marginals<double>((const double*)power, C, B, n, (double*)power_time, pb, ps, st));
+  else
+    QI_TRY(launch_power_marginals<float>((const float*)power, C, B, n, (float*)power_time, pb, ps, st));
+  return launch_finalize(power_band ? pb : nullptr, stats ? ps : nullptr, (double*)power_band, (double*)stats, C, B,
+                         nblk, nblk, st);
+}
+
+int qi_log2_offset(int dtype, int device, const void* in, void* out, int64_t C, int64_t count, double eps,
+                   const void* ref, qi_stream stream) {
+  QI_REQUIRE(in && out, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && count > 0, "bad shape");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? launch_log2_offset<double>((const double*)in, (double*)out, C, count, eps,
+                                                      (const double*)ref, (hipStream_t)stream)
+                         : launch_log2_offset<float>((const float*)in, (float*)out, C, count, (float)eps,
+                                                     (const double*)ref, (hipStream_t)stream);
+}
+
+int qi_shannon_panel(int dtype, int device, const void* power, const void* mult, int mode, int64_t C, int64_t B,
+                     int64_t n, double deg_free, void* info, void* shannon_bits, void* isnr, void* esnr,
+                     qi_stream stream) {
+  QI_REQUIRE(power && mult, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(mode >= 0 && mode <= 2, "bad mode %d", mode);
+  QI_REQUIRE(C > 0 && B > 0 && n > 0 && deg_free > 1.0, "bad shape");
+  DeviceGuard g(device);
+  return dtype == QI_F64
+             ? launch_shannon<double>((const double*)power, (const double*)mult, mode, C, B, n, deg_free,
+                                      (double*)info, (double*)shannon_bits, (double*)isnr, (double*)esnr,
+                                      (hipStream_t)stream)
+             : launch_shannon<float>((const float*)power, (const float*)mult, mode, C, B, n, deg_free, (float*)info,
+                                     (float*)shannon_bits, (float*)isnr, (float*)esnr, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Shared helpers for libqi_tfr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "qi_tfr.h"
+
+namespace qi {
+
+void set_error(const char* fmt, ...);
+
+#define QI_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      ::qi::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+      return QI_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define QI_FFT(call)                                                              \
+  do {                                                                            \
+    hipfftResult r_ = (call);                                                     \
+    if (r_ != HIPFFT_SUCCESS) {                                                   \
+      ::qi::set_error("%s:%d %s -> hipfft %d", __FILE__, __LINE__, #call, (int)r_); \
+      return QI_ERR_FFT;                                                          \
+    }                                                                             \
+  } while (0)
+
+#define QI_TRY(call)        \
+  do {                      \
+    int s_ = (call);        \
+    if (s_ != QI_OK) return s_; \
+  } while (0)
+
+#define QI_REQUIRE(cond, ...)       \
+  do {                              \
+    if (!(cond)) {                  \
+      ::qi::set_error(__VA_ARGS__); \
+      return QI_ERR_ARG;            \
+    }                               \
+  } while (0)
+
+template <typename T>
+struct c2;
+template <>
+struct c2<float> {
+  using type = float2;
+};
+template <>
+struct c2<double> {
+  using type = double2;
+};
+template <typename T>
+using cplx = typename c2<T>::type;
+
+template <typename T>
+__host__ __device__ inline cplx<T> mk(T re, T im) {
+  cplx<T> v;
+  v.x = re;
+  v.y = im;
+  return v;
+}
+template <typename C>
+__host__ __device__ inline C cmul(C a, C b) {
+  C r;
+  r.x = a.x * b.x - a.y * b.y;
+  r.y = a.x * b.y + a.y * b.x;
+  return r;
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int64_t next_pow2(int64_t v) {
+  int64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// Time samples one epilogue workgroup owns (256 threads x 4 consecutive samples).
+constexpr int kEpiThreads = 256;
+constexpr int kEpiVec = 4;
+constexpr int kEpiSpan = kEpiThreads * kEpiVec;
+
+// ---- launchers implemented in qi_kernels.hip (all asynchronous on `st`) ------------------------
+template <typename T>
+int launch_pack_pad(const T* sig, cplx<T>* X, int64_t C, int64_t n, int64_t L, hipStream_t st);
+
+int launch_bank_rows(double2* rows, int64_t n, int64_t L, int circular, const double* p_re, const double* p_im,
+                     const double* omega, const double* amp, int j0, int nb, hipStream_t st);
+template <typename T>
+int launch_bank_convert(const double2* F, cplx<T>* bank, int64_t count, int conj, double scale, hipStream_t st);
+
+template <typename T>
+int launch_mul_bank(const cplx<T>* X, const cplx<T>* H, cplx<T>* Y, int64_t Ct, int64_t Bt, int64_t L, hipStream_t st);
+template <typename T>
+int launch_stx_window(const cplx<T>* X, cplx<T>* Y, int64_t Ct, int64_t Bt, int64_t n, const int64_t* idx,
+                      const double* coef, hipStream_t st);
+
+template <typename T>
+struct EpiArgs {
+  const cplx<T>* Y;  // [Ct][Bt][L]
+  int64_t L, n, off; // out[t] = Y[(t + off) mod L]
+  int64_t Ct, Bt;    // tile extents
+  int64_t B;         // bands in the whole panel
+  int64_t j0;        // first band of this tile
+  cplx<T>* coef;     // [Ct][B][n] (already offset to the tile's first channel) or null
+  T* bits;           // idem
+  T* power_time;     // [Ct][n] or null
+  double* part_band; // [Ct][B][nblk] or null
+  double* part_stat; // [Ct][ntile_b][nblk][3] or null
+  int64_t tile_b;    // index of this band tile
+  int64_t ntile_b;
+  T power_scale;
+  T eps;
+};
+template <typename T>
+int launch_epilogue(const EpiArgs<T>& a, hipStream_t st);
+int launch_finalize(const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t C,
+                    int64_t B, int64_t nblk, int64_t nstat, hipStream_t st);
+
+template <typename T>
+int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                       int64_t nfft, int64_t nseg, hipStream_t st);
+template <typename T>
+int launch_stft_transpose(const cplx<T>* F, cplx<T>* Z, T* bits, int64_t C, int64_t nseg, int64_t nf, T scale, T eps,
+                          hipStream_t st);
+
+template <typename T>
+int launch_power_marginals(const T* P, int64_t C, int64_t B, int64_t n, T* power_time, double* part_band,
+                           double* part_stat, hipStream_t st);
+template <typename T>
+int launch_log2_offset(const T* in, T* out, int64_t C, int64_t count, T eps, const double* ref, hipStream_t st);
+template <typename T>
+int launch_shannon(const T* P, const T* mult, int mode, int64_t C, int64_t B, int64_t n, double deg, T* info, T* sb,
+                   T* isnr, T* esnr, hipStream_t st);
+
+}  // namespace qi

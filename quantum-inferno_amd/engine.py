@@ -1,0 +1,298 @@
+"""
+Batched GPU engine behind the reference-signature wrappers.
+
+A `TfrPlan` owns one qi_plan (include/qi_tfr.h): record length n, arithmetic type, device, the
+Gabor atom banks and the Stockwell band table.  Band selection is done here on the host in
+float64 (scales_dyadic) and handed to the library as tables; everything that touches a panel
+runs in libqi_tfr.so.  Signals are [channels, n]; panels are [channels, bands, n].
+
+PyTorch is used for device memory and streams only.
+"""
+import collections
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import scales_dyadic as scales
+
+_EPI_SPAN = 1024  # time samples per epilogue workgroup (csrc/qi_common.hpp:kEpiSpan)
+
+
+def _real_dtype(dtype):
+    if dtype in (torch.float32, np.float32, "float32", "f32"):
+        return torch.float32
+    if dtype in (torch.float64, np.float64, "float64", "f64", float):
+        return torch.float64
+    raise TypeError(f"unsupported dtype {dtype}: float32 or float64")
+
+
+def _complex_of(rdtype):
+    return torch.complex64 if rdtype == torch.float32 else torch.complex128
+
+
+def default_device():
+    _lib.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def as_signal(sig, device=None, dtype=None):
+    """-> (tensor [C, n] on the GPU, was_numpy, was_1d).  float32 stays float32, everything else
+    becomes float64 (the reference computes in float64)."""
+    was_numpy = not isinstance(sig, torch.Tensor)
+    if was_numpy:
+        arr = np.asarray(sig)
+        if arr.dtype != np.float32 and arr.dtype != np.float64:
+            arr = arr.astype(np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+    else:
+        t = sig
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.to(torch.float64)
+    if dtype is not None:
+        t = t.to(_real_dtype(dtype))
+    if device is None:
+        device = t.device if t.is_cuda else default_device()
+    t = t.to(device)
+    was_1d = t.dim() == 1
+    if was_1d:
+        t = t.unsqueeze(0)
+    if t.dim() != 2:
+        raise ValueError(f"signal must be 1-D [n] or 2-D [channels, n], got shape {tuple(t.shape)}")
+    return t.contiguous(), was_numpy, was_1d
+
+
+@dataclass
+class TfrResult:
+    """Outputs of one transform call; every field is a device tensor or None."""
+
+    frequency_hz: np.ndarray
+    coef: Optional[torch.Tensor] = None  # [C, B, n] complex
+    bits: Optional[torch.Tensor] = None  # [C, B, n] log2(|z| + eps)
+    power_band: Optional[torch.Tensor] = None  # [C, B] float64, sum over time of P
+    power_time: Optional[torch.Tensor] = None  # [C, n], sum over bands of P
+    stats: Optional[torch.Tensor] = None  # [C, 4] float64: max P, sum P, sum P log2 P, 0
+    power_scale: float = 1.0
+
+    @property
+    def max_power(self):
+        return self.stats[:, 0]
+
+    @property
+    def total_power(self):
+        return self.stats[:, 1]
+
+    @property
+    def entropy_bits(self):
+        """Total Shannon entropy sum(pdf * -log2(pdf)), pdf = P / sum(P), from the one-pass sums
+        H = log2 S - (sum P log2 P) / S (tfr_info.py:203-236 without materialising the panel; the
+        reference's eps64 inside the log changes H by < 1e-8 bits)."""
+        s = self.stats[:, 1]
+        return torch.log2(s) - self.stats[:, 2] / s
+
+    def power_per_band_bits(self):
+        """log2(sum_t P + eps) - max   (tfr_info.py:93)."""
+        b = torch.log2(self.power_band + float(scales.EPSILON64))
+        return b - b.max(dim=1, keepdim=True).values
+
+    def power_per_time_bits(self):
+        """log2(sum_j P + eps) - max   (tfr_info.py:91)."""
+        b = torch.log2(self.power_time.to(torch.float64) + float(scales.EPSILON64))
+        return b - b.max(dim=1, keepdim=True).values
+
+
+def styx_bank_tables(order, n, fs, dictionary_type="norm"):
+    """Host float64 tables of the styx_cwt Gabor bank (styx_cwt.py:29-40,68-144):
+    returns (f_hz, p_re, p_im, omega, amp, scale)."""
+    f_hz = scales.log_frequency_hz_from_fft_points(fs, n, order)
+    scale, omega = scales.scale_from_frequency_hz(order, f_hz, fs)
+    amp_norm = (np.pi * scale ** 2) ** (-1 / 4)
+    if dictionary_type == "spect":
+        amp = (4 * np.pi * scale ** 2) ** (-1 / 4) * amp_norm
+    elif dictionary_type == "unit":
+        amp = np.ones(scale.shape)
+    else:
+        amp = amp_norm
+    return f_hz, 0.5 / scale ** 2, np.zeros_like(scale), omega, amp, scale
+
+
+class TfrPlan:
+    """GPU plan for records of n samples."""
+
+    def __init__(self, n, dtype=torch.float32, device=None, workspace_bytes=None, engine=_lib.QI_ENGINE_AUTO):
+        self._lib = _lib.require_gpu()
+        self.n = int(n)
+        self.rdtype = _real_dtype(dtype)
+        self.device = torch.device(device) if device is not None else default_device()
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.workspace_bytes = int(workspace_bytes) if workspace_bytes else 0
+        self._handle = C.c_void_p()
+        desc = _lib.PlanDesc(
+            n=self.n,
+            dtype=_lib.QI_F64 if self.rdtype == torch.float64 else _lib.QI_F32,
+            device=self.device.index,
+            engine=engine,
+            reserved=0,
+            workspace_bytes=self.workspace_bytes,
+        )
+        _lib.check(self._lib.qi_plan_create(C.byref(self._handle), C.byref(desc)))
+        self.freq = {}  # bank name -> host band centre frequencies
+
+    # -- sizing -------------------------------------------------------------------------------
+    @staticmethod
+    def workspace_for(n, n_bands, dtype, channels=1, cap_bytes=8 << 30):
+        """Scratch that lets `channels` records of an n_bands panel go through in one tile."""
+        esz = 16 if _real_dtype(dtype) == torch.float64 else 8
+        length = 2 * n if (n & (n - 1)) == 0 else 1 << (2 * n - 2).bit_length()
+        nblk = -(-n // _EPI_SPAN)
+        per_chan = (n_bands + 1) * length * esz + n_bands * nblk * 32 + 4096
+        build = min(n_bands, 16) * length * 16
+        need = max(per_chan * channels, build, 1 << 24)
+        return int(min(max(need, per_chan), max(cap_bytes, per_chan)))
+
+    # -- tables -------------------------------------------------------------------------------
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def set_gabor_bank(self, which, f_hz, p_re, p_im, omega, amp):
+        keep = [_lib.darr(a) for a in (p_re, p_im, omega, amp)]
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self._lib.qi_plan_set_gabor_bank(
+                    self._handle, which, len(keep[0][0]), keep[0][1], keep[1][1], keep[2][1], keep[3][1], self._stream()
+                )
+            )
+        self.freq[which] = np.asarray(f_hz)
+
+    def set_styx_bank(self, order, fs, dictionary_type="norm"):
+        f_hz, p_re, p_im, omega, amp, _ = styx_bank_tables(order, self.n, fs, dictionary_type)
+        self.set_gabor_bank(_lib.QI_BANK_STYX, f_hz, p_re, p_im, omega, amp)
+        return f_hz
+
+    def set_stx_bands(self, order, fs):
+        """Band table of styx_stx.stx_complex_any_scale_pow2 (styx_stx.py:207-219,233)."""
+        f_hz = scales.log_frequency_hz_from_fft_points(fs, self.n, order)
+        idx = scales.stx_shift_indices(f_hz, self.n, fs)
+        sigma = scales.cycles_from_order(order) / (2 * np.pi * f_hz / fs)
+        ia, ip = _lib.iarr(idx)
+        sa, sp = _lib.darr(sigma)
+        _lib.check(self._lib.qi_plan_set_stx_bands(self._handle, len(ia), ip, sp))
+        self.freq[_lib.QI_TABLE_STX] = f_hz
+        self.stx_index = idx
+        return f_hz
+
+    # -- transforms ---------------------------------------------------------------------------
+    def _run(self, which, sig, coef, bits, reductions, power_scale, eps):
+        if sig.dtype != self.rdtype or not sig.is_cuda or sig.device != self.device:
+            sig = sig.to(device=self.device, dtype=self.rdtype)
+        sig = sig.contiguous()
+        if sig.dim() != 2 or sig.shape[1] != self.n:
+            raise ValueError(f"signal must be [channels, {self.n}], got {tuple(sig.shape)}")
+        n_ch = sig.shape[0]
+        f_hz = self.freq.get(which)
+        if f_hz is None:
+            raise _lib.QiError("band table not set on this plan")
+        n_b = len(f_hz)
+        dev = self.device
+        res = TfrResult(frequency_hz=f_hz, power_scale=power_scale)
+        if coef:
+            res.coef = torch.empty((n_ch, n_b, self.n), dtype=_complex_of(self.rdtype), device=dev)
+        if bits:
+            res.bits = torch.empty((n_ch, n_b, self.n), dtype=self.rdtype, device=dev)
+        if reductions:
+            res.power_band = torch.empty((n_ch, n_b), dtype=torch.float64, device=dev)
+            res.power_time = torch.empty((n_ch, self.n), dtype=self.rdtype, device=dev)
+            res.stats = torch.empty((n_ch, 4), dtype=torch.float64, device=dev)
+        out = _lib.TfrOut(
+            coef=_lib.ptr(res.coef),
+            bits=_lib.ptr(res.bits),
+            power_band=_lib.ptr(res.power_band),
+            power_time=_lib.ptr(res.power_time),
+            stats=_lib.ptr(res.stats),
+            power_scale=float(power_scale),
+            eps=float(eps),
+        )
+        with torch.cuda.device(dev):
+            if which == _lib.QI_TABLE_STX:
+                rc = self._lib.qi_stx(self._handle, _lib.ptr(sig), n_ch, C.byref(out), self._stream())
+            else:
+                rc = self._lib.qi_cwt(self._handle, which, _lib.ptr(sig), n_ch, C.byref(out), self._stream())
+        _lib.check(rc)
+        return res
+
+    def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
+        return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps)
+
+    def cwt_atoms(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
+        return self._run(_lib.QI_BANK_ATOMS, sig, coef, bits, reductions, power_scale, eps)
+
+    def stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
+        return self._run(_lib.QI_TABLE_STX, sig, coef, bits, reductions, power_scale, eps)
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.qi_plan_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- small LRU of plans for the reference-signature wrappers (each call there is one record) ----
+_PLANS = collections.OrderedDict()
+_MAX_PLANS = 3
+
+
+def cached_plan(key, factory):
+    plan = _PLANS.pop(key, None)
+    if plan is None:
+        plan = factory()
+        while len(_PLANS) >= _MAX_PLANS:
+            _, old = _PLANS.popitem(last=False)
+            old.close()
+    _PLANS[key] = plan
+    return plan
+
+
+def clear_plans():
+    while _PLANS:
+        _, old = _PLANS.popitem()
+        old.close()
+
+
+def gabor_atoms(n, p_re, p_im, omega, amp, device=None):
+    """[B, n] complex128 device tensor of time-domain atoms (qi_gabor_atoms)."""
+    lib = _lib.require_gpu()
+    dev = torch.device(device) if device is not None else default_device()
+    keep = [_lib.darr(a) for a in (p_re, p_im, omega, amp)]
+    out = torch.empty((len(keep[0][0]), n), dtype=torch.complex128, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            lib.qi_gabor_atoms(
+                dev.index if dev.index is not None else torch.cuda.current_device(),
+                n,
+                len(keep[0][0]),
+                keep[0][1],
+                keep[1][1],
+                keep[2][1],
+                keep[3][1],
+                _lib.ptr(out),
+                _lib.stream_ptr(dev),
+            )
+        )
+    return out
+
+
+def finish(result_tensor, was_numpy, was_1d):
+    """Undo as_signal's batching / device move on an output."""
+    if result_tensor is None:
+        return None
+    t = result_tensor[0] if was_1d else result_tensor
+    return t.cpu().numpy() if was_numpy else t

@@ -1,0 +1,263 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI by the reference-signature
+wrappers, against (1) golden vectors captured from the reference itself, (2) the CPU oracle on the
+same seeded inputs, (3) size-independent properties at the benchmark size.
+
+Stated tolerances (max|delta| relative to max|reference| of the panel unless noted):
+  float64 path : 1e-10 coefficients, 1e-8 log2 bits where |z| >= 1e-6 max, 1e-10 reductions
+  float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-2 max, 1e-4 reductions
+Band tables, shift indices, STFT shapes / time / frequency axes: bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relmax
+from oracle import tfr_oracle as orc
+
+import quantum_inferno_amd as qi
+from quantum_inferno_amd import cwt_atoms, engine, styx_cwt, styx_fft, styx_stx, tfr_info
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: dict(coef=1e-10, bits=1e-8, bits_floor=1e-6, red=1e-10),
+       np.float32: dict(coef=2e-5, bits=1e-3, bits_floor=1e-2, red=1e-4)}
+
+
+def check_bits(bits, ref_coef, tol):
+    mag = np.abs(ref_coef)
+    sel = mag >= tol["bits_floor"] * mag.max()
+    ref_bits = np.log2(mag + orc.EPS64)
+    assert np.max(np.abs(bits - ref_bits)[sel]) <= tol["bits"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("key,order,fs", [("o3_fs1000", 3, 1000.0), ("o12_fs800", 12, 800.0)])
+def test_small_panels_vs_reference(golden, key, order, fs, dtype):
+    g = golden("small_n1024.npz")
+    tol = TOL[dtype]
+    sig = g[f"sig_{key}"].astype(dtype)
+    f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
+    assert np.array_equal(f, g[f"f_{key}"]) and np.array_equal(t, g[f"t_{key}"])
+    assert cwt.dtype == (np.complex128 if dtype == np.float64 else np.complex64)
+    assert relmax(cwt, g[f"cwt_norm_{key}"]) <= tol["coef"]
+    f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
+    assert np.array_equal(f2, f) and np.array_equal(t2, t)
+    assert relmax(stx, g[f"stx_{key}"]) <= tol["coef"]
+    c, bits, tc, fc = cwt_atoms.cwt_chirp_from_sig(sig, fs, order)
+    assert np.array_equal(fc, g[f"chirp_f_{key}"]) and np.array_equal(tc, t)
+    assert relmax(c, g[f"chirp_cwt_{key}"]) <= tol["coef"]
+    check_bits(bits, g[f"chirp_cwt_{key}"], tol)
+    if order == 3:
+        _, _, spect = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs, dictionary_type="spect")
+        assert relmax(spect, g[f"cwt_spect_{key}"]) <= tol["coef"]
+        c2 = cwt_atoms.cwt_chirp_from_sig(sig, fs, order, dictionary_type="spect")[0]
+        assert relmax(c2, g[f"chirp_cwt_spect_{key}"]) <= tol["coef"]
+        c3 = cwt_atoms.cwt_chirp_from_sig(sig, fs, order, cwt_type="conv")[0]
+        assert relmax(c3, g[f"chirp_cwt_conv_{key}"]) <= tol["coef"]
+
+
+def test_atom_bank_rows_vs_reference(golden):
+    g = golden("small_n1024.npz")
+    for key, order, fs in (("o3_fs1000", 3, 1000.0), ("o12_fs800", 12, 800.0)):
+        f = g[f"f_{key}"]
+        atoms, t_c, scale, omega, amp = styx_cwt.wavelet_centered_4cwt(order, 1024, f, fs, "norm")
+        sel = [0, len(f) // 2, len(f) - 1]
+        assert relmax(atoms[sel], g[f"atoms_{key}"]) <= 1e-12
+        assert scale.shape == atoms.shape and np.array_equal(scale[:, 0], g[f"atom_scale_{key}"])
+        assert np.array_equal(amp[:, 7], g[f"atom_amp_{key}"])
+        one, _, s1, w1, a1 = styx_cwt.wavelet_centered_4cwt(order, 1024, float(f[3]), fs, "norm")
+        assert one.shape == (1024,) and relmax(one, atoms[3]) <= 1e-15
+        ref_chirp = orc.chirp_atom(order, 1024, f[3], fs)
+        got, _ = cwt_atoms.chirp_centered_4cwt(order, np.zeros(1024), f[3], fs)
+        assert relmax(got, ref_chirp) <= 1e-12
+
+
+@pytest.mark.parametrize("tag", ["n13_fs1000", "n13_fs800", "n16_fs1000"])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("order", [3, 12])
+def test_stft_vs_reference(golden, tag, dtype, order):
+    g = golden("stft.npz")
+    tol = TOL[np.dtype(dtype).type]
+    fs = float(tag.split("fs")[1])
+    sig = g[f"sig_{tag}_{dtype}"]
+    z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
+    key = f"{tag}_{dtype}_o{order}"
+    assert np.array_equal(np.array(z.shape), g[f"shape_{key}"])
+    assert np.array_equal(t, g[f"t_{key}"]) and np.array_equal(f, g[f"f_{key}"])
+    gz = g[f"z_{key}"]
+    step = 1 if gz.shape[1] == z.shape[1] else 8
+    assert z.dtype == gz.dtype
+    assert relmax(z[:, ::step], gz) <= tol["coef"]
+    check_bits(bits[:, ::step], gz, tol)
+
+
+def test_stft_2d_batch_and_errors(golden):
+    g = golden("stft.npz")
+    f, t, z = styx_fft.stft_complex_pow2(g["sig_2d"], 1000.0, 256)
+    assert np.array_equal(f, g["f_2d"]) and np.array_equal(t, g["t_2d"])
+    assert z.shape == g["z_2d_alpha025"].shape and relmax(z, g["z_2d_alpha025"]) <= 1e-10
+    with pytest.raises(ValueError):
+        styx_fft.stft_from_sig(np.zeros(1024), 1000.0, 12)  # ref styx_fft.py:42-45
+    # Gaussian-window variant against the oracle's spectral helper
+    sig = g["sig_2d"][0]
+    f2, t2, zg = styx_fft.gtx_complex_pow2(sig, 1000.0, 256)
+    k = np.arange(0, 257) - 128.0
+    ref = orc.stft_spectral(sig, 1000.0, np.exp(-(k ** 2) / (2 * 64.0 * 64.0))[:-1], 256, 128, 256)
+    assert np.array_equal(t2, ref[1]) and relmax(zg, ref[2]) <= 1e-10
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tfr_info_vs_reference(golden, dtype):
+    g = golden("small_n1024.npz")
+    tol = TOL[dtype]
+    p = g["info_power"].astype(dtype)
+    bits, per_time, per_freq = tfr_info.power_dynamics_scaled_bits(p)
+    atol = 1e-9 if dtype == np.float64 else 2e-4
+    assert np.max(np.abs(bits - g["info_bits"])) <= atol * 40
+    assert np.max(np.abs(per_time - g["info_bits_time"])) <= atol * 40
+    assert np.max(np.abs(per_freq - g["info_bits_freq"])) <= atol * 40
+    assert np.max(np.abs(tfr_info.scale_power_bits(p) - g["info_bits"])) <= atol * 40
+    for nm, obj in (("tot", tfr_info.shannon_stft_from_tfr_power(p)), ("time", tfr_info.ShannonStftPerTime(p)),
+                    ("freq", tfr_info.ShannonStftPerFreq(p))):
+        assert np.max(np.abs(obj.info - g[f"sh_{nm}_info"])) <= atol * 40, nm
+        assert relmax(obj.shannon_bits, g[f"sh_{nm}_bits"]) <= tol["red"], nm
+        assert obj.ref_bits == float(g[f"sh_{nm}_ref"])
+        assert np.max(np.abs(obj.isnr - g[f"sh_{nm}_isnr"])) <= atol * 40, nm
+        assert relmax(obj.esnr, g[f"sh_{nm}_esnr"]) <= tol["red"], nm
+    # 1-D marginal input and a pdf handed in directly
+    assert np.max(np.abs(tfr_info.scale_power_bits(p.sum(axis=0)) - g["info_bits_time"])) <= atol * 40
+    direct = tfr_info.ShannonStft((g["info_power"] / g["info_power"].sum()).astype(dtype), p.size)
+    assert relmax(direct.shannon_bits, g["sh_tot_bits"]) <= tol["red"]
+
+
+def _plan_with_all(n, fs, order, dtype, channels=1, workspace=None):
+    f = qi.scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
+    ws = workspace or engine.TfrPlan.workspace_for(n, len(f), dtype, channels)
+    plan = engine.TfrPlan(n, dtype, None, ws)
+    plan.set_styx_bank(order, fs)
+    plan.set_stx_bands(order, fs)
+    return plan
+
+
+def check_digest(res, g, prefix, order, tol, rows):
+    coef = res.coef[0].cpu().numpy()
+    tsel = g[f"{prefix}_tsel_o{order}"]
+    ref_rows = g[f"{prefix}_rows_o{order}"]
+    got = coef[rows][:, tsel] if ref_rows.shape[1] != coef.shape[1] else coef[rows]
+    scale = np.sqrt(float(g[f"{prefix}_pmax_o{order}"]))
+    assert np.max(np.abs(got - ref_rows)) / scale <= tol["coef"]
+    pb = res.power_band[0].cpu().numpy()
+    ref_pb = g[f"{prefix}_psum_band_o{order}"]
+    assert np.max(np.abs(pb - ref_pb)) / ref_pb.max() <= tol["red"]
+    pt = res.power_time[0].cpu().numpy().astype(np.float64)
+    ref_pt = g[f"{prefix}_psum_time_o{order}"]
+    pt = pt[tsel] if ref_pt.shape[0] != pt.shape[0] else pt
+    assert np.max(np.abs(pt - ref_pt)) / ref_pt.max() <= tol["red"]
+    st = res.stats[0].cpu().numpy()
+    assert abs(st[0] - float(g[f"{prefix}_pmax_o{order}"])) / st[0] <= 10 * tol["coef"]
+    assert abs(st[1] - float(g[f"{prefix}_ptot_o{order}"])) / st[1] <= tol["red"]
+    ent = float(res.entropy_bits[0])
+    assert abs(ent - float(g[f"{prefix}_entropy_bits_o{order}"])) <= tol["red"] * 20
+
+
+@pytest.mark.parametrize("name,n,fs,orders", [("medium_n8192.npz", 8192, 1000.0, (3, 12)),
+                                               ("large_n65536.npz", 65536, 800.0, (3, 12))])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_reductions_vs_reference(golden, name, n, fs, orders, dtype):
+    g = golden(name)
+    tol = TOL[dtype]
+    sig = torch.from_numpy(g["sig"].astype(dtype)).cuda().unsqueeze(0)
+    for order in orders:
+        plan = _plan_with_all(n, fs, order, dtype)
+        assert np.array_equal(plan.freq[0], g[f"f_o{order}"])
+        rows = g[f"rows_o{order}"]
+        check_digest(plan.cwt(sig, coef=True, reductions=True), g, "cwt", order, tol, rows)
+        check_digest(plan.stx(sig, coef=True, reductions=True), g, "stx", order, tol, rows)
+        plan.close()
+        c, bits, _, fc = cwt_atoms.cwt_chirp_from_sig(sig[0], fs, order)
+        assert np.array_equal(fc, g[f"chirp_f_o{order}"])
+        got = c[torch.from_numpy(g[f"chirp_rowsel_o{order}"]).cuda()].cpu().numpy()
+        ref = g[f"chirp_rows_o{order}"]
+        got = got[:, g[f"chirp_tsel_o{order}"]] if ref.shape[1] != got.shape[1] else got
+        assert np.max(np.abs(got - ref)) / np.sqrt(float(g[f"chirp_pmax_o{order}"])) <= tol["coef"]
+        engine.clear_plans()
+
+
+def test_benchmark_size_vs_reference_and_properties(golden):
+    """Config 2 of BASELINE.json: 1 channel, 2^20 samples, order 3, float32."""
+    g = golden("large_n1048576.npz")
+    n, fs, order = 1 << 20, 1000.0, 3
+    tol = TOL[np.float32]
+    x = orc.synth_chirp(n, fs, dtype=np.float32)
+    assert np.max(np.abs(x[:: n // 4096] - g["sig_samples"])) <= 1e-6  # same seeded input as the fixture
+    sig = torch.from_numpy(x).cuda().unsqueeze(0)
+    plan = _plan_with_all(n, fs, order, np.float32)
+    rows = g["rows_o3"]
+    res_c = plan.cwt(sig, coef=True, reductions=True)
+    check_digest(res_c, g, "cwt", order, tol, rows)
+    res_s = plan.stx(sig, coef=True, reductions=True)
+    check_digest(res_s, g, "stx", order, tol, rows)
+    # fused reductions agree with a direct reduction of the stored panel
+    p = (res_s.coef[0].abs() ** 2).double()
+    assert torch.allclose(p.sum(dim=1), res_s.power_band[0], rtol=1e-5)
+    assert torch.allclose(p.sum(dim=0), res_s.power_time[0].double(), rtol=1e-4, atol=1e-6 * float(p.sum(dim=0).max()))
+    # linearity: T(a x + b y) = a T(x) + b T(y)
+    y = torch.from_numpy(orc.synth_chirp(n, fs, channel=1, n_channels=2, dtype=np.float32)).cuda().unsqueeze(0)
+    mix = 0.75 * sig - 1.5 * y
+    for fn in (plan.cwt, plan.stx):
+        a, b, m = fn(sig).coef, fn(y).coef, fn(mix).coef
+        lin = 0.75 * a - 1.5 * b
+        assert float((m - lin).abs().max() / lin.abs().max()) <= 4 * tol["coef"]
+        del a, b, m, lin
+    # Stockwell is covariant to circular time shifts: |STX(x shifted by s)| = |STX(x)| shifted by s
+    s = 12345
+    shifted = plan.stx(torch.roll(sig, s, dims=1)).coef
+    assert float((shifted.abs() - torch.roll(res_s.coef, s, dims=2).abs()).abs().max() / res_s.coef.abs().max()) <= 4 * tol["coef"]
+    plan.close()
+
+
+def test_batches_tiles_and_oracle_on_noise():
+    """Ragged cases: several channels, a workspace that forces band tiles and channel tiles,
+    a record length that is not a power of two, all-zero input."""
+    rng = np.random.default_rng(7)
+    n, fs, order = 4096, 1000.0, 6
+    x = rng.standard_normal((5, n))
+    ref_c = np.stack([orc.cwt_fft(order, xi, fs)[2] for xi in x])
+    ref_s = np.stack([orc.stx_fft(order, xi, fs)[2] for xi in x])
+    f, _, c = styx_cwt.cwt_complex_any_scale_pow2(order, x, fs)
+    assert c.shape == ref_c.shape and relmax(c, ref_c) <= 1e-10
+    _, _, s = styx_stx.stx_complex_any_scale_pow2(order, x, fs)
+    assert relmax(s, ref_s) <= 1e-10
+    # tiny workspace: 1 channel x 5 bands per tile
+    small = 7 * 2 * n * 16 + len(f) * 4 * 32 + 8192
+    plan = _plan_with_all(n, fs, order, np.float64, workspace=small)
+    xt = torch.from_numpy(x).cuda()
+    r = plan.cwt(xt, coef=True, bits=True, reductions=True)
+    assert relmax(r.coef.cpu().numpy(), ref_c) <= 1e-10
+    p = np.abs(ref_c) ** 2
+    assert np.allclose(r.power_band.cpu().numpy(), p.sum(axis=2), rtol=1e-10)
+    assert np.allclose(r.power_time.cpu().numpy(), p.sum(axis=1), rtol=1e-10)
+    assert np.allclose(r.stats[:, 0].cpu().numpy(), p.max(axis=(1, 2)), rtol=1e-10)
+    ent = [np.sum(orc.shannon_from_power(pi).shannon_bits) for pi in p]
+    assert np.allclose(r.entropy_bits.cpu().numpy(), ent, rtol=1e-10)
+    r2 = plan.stx(xt, coef=True, reductions=True)
+    assert relmax(r2.coef.cpu().numpy(), ref_s) <= 1e-10
+    zero = plan.cwt(torch.zeros((1, n), dtype=torch.float64, device="cuda"), coef=True, reductions=True)
+    assert float(zero.coef.abs().max()) == 0.0 and float(zero.stats[0, 1]) == 0.0
+    plan.close()
+    # n not a power of two goes through the same path with hipFFT sizes
+    m = 3000
+    xm = rng.standard_normal(m)
+    assert relmax(styx_cwt.cwt_complex_any_scale_pow2(3, xm, fs)[2], orc.cwt_fft(3, xm, fs)[2]) <= 1e-10
+    assert relmax(styx_stx.stx_complex_any_scale_pow2(3, xm, fs)[2], orc.stx_fft(3, xm, fs)[2]) <= 1e-10
+    assert relmax(cwt_atoms.cwt_chirp_from_sig(xm, fs, 3)[0], orc.cwt_chirp_fft(xm, fs, 3)[0]) <= 1e-10
+    # index_shift != 0 (chirped atoms, complex p)
+    ref = orc.cwt_chirp_fft(x[0], fs, 3, index_shift=1.0)[0]
+    assert relmax(cwt_atoms.cwt_chirp_from_sig(x[0], fs, 3, index_shift=1.0)[0], ref) <= 1e-10
+    with pytest.raises(ValueError):
+        styx_cwt.cwt_complex_any_scale_pow2(3, x[0], fs, cwt_type="morlet2")
+    with pytest.raises(ValueError):
+        cwt_atoms.cwt_chirp_from_sig(x[0], fs, 3, cwt_type="nope")
+    # CUDA tensor in -> CUDA tensor out
+    out = styx_stx.stx_complex_any_scale_pow2(order, xt[0], fs)[2]
+    assert isinstance(out, torch.Tensor) and out.is_cuda and out.shape == ref_s[0].shape

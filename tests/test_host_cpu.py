@@ -1,0 +1,110 @@
+"""CPU-only checks of the host side of the product: band / index tables bit-exact against the
+golden vectors, windows against SciPy, the C-ABI library loads and exports every symbol the header
+declares, and the transforms refuse to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import quantum_inferno_amd as qi
+from quantum_inferno_amd import _lib, cwt_atoms, scales_dyadic as sd, styx_fft
+from quantum_inferno_amd.utilities import calculations, matrix, rescaling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_known_answer_of_reference_tests():
+    # reference tests/test_scales_dyadic.py:8-21 (commented out upstream)
+    f = sd.log_frequency_hz_from_fft_points(100.0, 8192, 6, 1.0, sd.Slice.G3)
+    assert len(f) == 48 and f[0] == 0.1778279410038923 and f[-1] == 39.810717055349706
+    # reference tests/utilities/test_rescaling.py:7-21, test_calculations.py:86-100
+    assert round(float(rescaling.to_log2_with_epsilon(100.0)), 2) == 6.64
+    assert round(float(rescaling.to_log2_with_epsilon(-100.0)), 2) == 6.64
+    assert rescaling.is_power_of_two(8) and not rescaling.is_power_of_two(9)
+    assert calculations.round_value(1.5, "round") == 2
+    assert calculations.get_num_points(10, 10, "round", "log2") == 7
+    with pytest.raises(ValueError):
+        calculations.round_value(1.5, "nearest")
+    with pytest.raises(ValueError):
+        calculations.get_num_points(10, 10, "round", "bits")
+
+
+def test_band_tables_bit_exact(golden):
+    g = golden("bands.npz")
+    for key in g["combos"]:
+        fs_s, n_s, o_s = str(key).split("_")
+        fs, n, order = float(fs_s[2:]), 2 ** int(n_s[1:]), int(o_s[1:])
+        f = sd.log_frequency_hz_from_fft_points(fs, n, order)
+        assert np.array_equal(f, g[f"f_{key}"]), key
+        assert np.array_equal(sd.stx_shift_indices(f, n, fs), g[f"idx_{key}"]), key
+        assert np.array_equal(sd.scale_from_frequency_hz(order, f, fs)[0], g[f"scale_{key}"]), key
+        _, f_min = cwt_atoms.chirp_scales_from_duration(order, n / fs)
+        out = cwt_atoms.chirp_frequency_bands(order, f_min, fs, fs / 2.0)
+        assert np.array_equal(np.flip(out[4]), g[f"chirpf_{key}"]), key
+        assert np.array_equal(np.array(out[:4], dtype=np.float64), g[f"chirpmq_{key}"]), key
+
+
+def test_scalars_bit_exact(golden):
+    g = golden("bands.npz")
+    for fs, order, seg in g["stft_seg"]:
+        assert styx_fft.stft_segment_points(fs, order) == int(seg)
+    with pytest.warns(UserWarning):
+        assert sd.cycles_from_order(0.5) == g["cycles"][0]
+    assert np.array_equal(np.array([sd.cycles_from_order(o) for o in (0.75, 1, 3, 6, 12, 24)]), g["cycles"][1:])
+    assert np.array_equal(np.array([cwt_atoms.chirp_mqg_from_n(o) for o in (1, 3, 6, 12, 24)]), g["mqg"])
+    assert sd.get_epsilon() == 2.220446049250313e-16
+
+
+def test_windows_match_scipy():
+    import scipy.signal as ss
+
+    for m in (64, 256, 512, 2048, 1000):
+        for alpha in (0.0, 0.25, 0.5, 1.0):
+            assert np.array_equal(styx_fft.tukey_window_periodic(m, alpha), ss.get_window(("tukey", alpha), m)), (m, alpha)
+        assert np.array_equal(styx_fft.gaussian_window_periodic(m, m // 4), ss.get_window(("gaussian", m // 4), m))
+
+
+def test_tile_multiplies():
+    a = np.arange(12.0).reshape(3, 4)
+    assert np.array_equal(matrix.d0tile_x_d0d1(np.array([1.0, 2.0, 3.0]), a), np.array([1.0, 2.0, 3.0])[:, None] * a)
+    assert np.array_equal(matrix.d1tile_x_d0d1(np.arange(4.0), a), np.arange(4.0)[None, :] * a)
+    with pytest.raises(TypeError):
+        matrix.d0tile_x_d0d1(np.arange(4.0), a)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "qi_tfr.h")).read()
+    declared = set(re.findall(r"\b(qi_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    assert lib.qi_abi_version() == 1
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/qi_tfr.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    # pure-host entry points may be called without a GPU
+    assert lib.qi_stft_segments(65536, 512, 256) == 257
+    assert lib.qi_stft_segments(65536, 2048, 1024) == 65
+    assert lib.qi_stft_segments(8192, 512, 256) == 33
+
+
+def test_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.QiError):
+        qi.styx_stx.stx_complex_any_scale_pow2(3, np.zeros(1024), 1000.0)
+    with pytest.raises(_lib.QiError):
+        qi.styx_cwt.cwt_complex_any_scale_pow2(3, np.zeros(1024), 1000.0)
+    with pytest.raises(_lib.QiError):
+        qi.tfr_info.scale_power_bits(np.ones((4, 16)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "quantum-inferno_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.lower(), f"{fn} mentions the oracle"

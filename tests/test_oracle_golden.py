@@ -1,0 +1,147 @@
+"""Pins the CPU oracle (oracle/tfr_oracle.py) to outputs of the reference itself
+(tests/golden/*.npz, written by oracle/gen_golden.py in the build container) and to the
+reference's one known-answer vector for this path.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import tfr_oracle as orc
+from conftest import relmax
+
+
+def test_reference_known_answer(golden):
+    # reference tests/test_scales_dyadic.py:8-21 (commented out upstream): 100 Hz, 8192 points, order 6
+    f = orc.band_table(100.0, 8192, 6, 1.0, orc.G3)
+    assert len(f) == 48
+    assert f[0] == 0.1778279410038923
+    assert f[-1] == 39.810717055349706
+    assert np.array_equal(f, golden("bands.npz")["kat_100hz_8192_n6"])
+
+
+def test_band_tables_bit_exact(golden):
+    g = golden("bands.npz")
+    for key in g["combos"]:
+        fs_s, n_s, o_s = str(key).split("_")
+        fs, n, order = float(fs_s[2:]), 2 ** int(n_s[1:]), int(o_s[1:])
+        f = orc.band_table(fs, n, order)
+        assert np.array_equal(f, g[f"f_{key}"]), key
+        assert np.array_equal(orc.stx_indices(f, n, fs), g[f"idx_{key}"]), key
+        assert np.array_equal(orc.scale_omega(order, f, fs)[0], g[f"scale_{key}"]), key
+        order_n, f_chirp = orc.chirp_band_table(order, n, fs)
+        assert np.array_equal(np.flip(f_chirp), g[f"chirpf_{key}"]), key
+        mqg = orc.chirp_mqg_from_n(order_n)
+        assert np.array_equal(np.array([order_n, mqg[0], mqg[1], mqg[2]]), g[f"chirpmq_{key}"]), key
+
+
+def test_scalars_bit_exact(golden):
+    g = golden("bands.npz")
+    for fs, order, seg in g["stft_seg"]:
+        assert orc.stft_segment_points(fs, order) == int(seg)
+    assert np.array_equal(np.array([orc.cycles_from_order(o) for o in (0.5, 0.75, 1, 3, 6, 12, 24)]), g["cycles"])
+    assert np.array_equal(np.array([orc.chirp_mqg_from_n(o) for o in (1, 3, 6, 12, 24)]), g["mqg"])
+    assert np.array_equal(orc.to_log2_with_epsilon(np.array([100.0, -100.0])), g["log2eps_pm100"])
+    # reference tests/utilities/test_calculations.py:86-100, test_rescaling.py:7-21
+    assert orc.get_num_points(10, 10, "round", "log2") == 7
+    assert orc.round_value(1.5, "round") == 2 and orc.round_value(1.5, "floor") == 1
+    assert abs(orc.to_log2_with_epsilon(100.0) - 6.64) < 0.01
+
+
+@pytest.mark.parametrize("key,order,fs", [("o3_fs1000", 3, 1000.0), ("o12_fs800", 12, 800.0)])
+def test_small_panels(golden, key, order, fs):
+    g = golden("small_n1024.npz")
+    sig = g[f"sig_{key}"]
+    f, t, cwt = orc.cwt_fft(order, sig, fs, "norm")
+    assert np.array_equal(f, g[f"f_{key}"]) and np.array_equal(t, g[f"t_{key}"])
+    assert relmax(cwt, g[f"cwt_norm_{key}"]) < 1e-14
+    sel = [0, len(f) // 2, len(f) - 1]
+    atoms = np.stack([orc.gabor_atom_row(order, len(sig), f[j], fs) for j in sel])
+    assert relmax(atoms, g[f"atoms_{key}"]) < 1e-15
+    s, _ = orc.scale_omega(order, f, fs)
+    assert np.array_equal(s, g[f"atom_scale_{key}"])
+    assert np.array_equal(orc.wavelet_amplitude(s)[0], g[f"atom_amp_{key}"])
+    f2, t2, stx = orc.stx_fft(order, sig, fs)
+    assert relmax(stx, g[f"stx_{key}"]) < 1e-14
+    c, bits, tc, fc = orc.cwt_chirp_fft(sig, fs, order)
+    assert np.array_equal(fc, g[f"chirp_f_{key}"])
+    assert relmax(c, g[f"chirp_cwt_{key}"]) < 1e-11
+    big = np.abs(g[f"chirp_cwt_{key}"]) > 1e-9
+    assert np.max(np.abs(bits - g[f"chirp_bits_{key}"])[big]) < 1e-6
+    if order == 3:
+        assert relmax(orc.cwt_fft(order, sig, fs, "spect")[2], g[f"cwt_spect_{key}"]) < 1e-14
+        assert relmax(orc.cwt_chirp_fft(sig, fs, order, dict_type="spect")[0], g[f"chirp_cwt_spect_{key}"]) < 1e-11
+
+
+def test_cwt_atoms_conv_backend_matches_away_from_edges(golden):
+    # the reference's own cross-check of its circular fft back-end (cwt_atoms.py:423-435)
+    g = golden("small_n1024.npz")
+    a, b = g["chirp_cwt_o3_fs1000"], g["chirp_cwt_conv_o3_fs1000"]
+    assert relmax(a[-12:, 256:768], b[-12:, 256:768]) < 1e-6
+
+
+def test_tfr_info(golden):
+    g = golden("small_n1024.npz")
+    p = g["info_power"]
+    a, b, c = orc.power_dynamics_scaled_bits(p)
+    assert np.array_equal(a, g["info_bits"]) and np.array_equal(b, g["info_bits_time"]) and np.array_equal(c, g["info_bits_freq"])
+    for nm, obj in (("tot", orc.shannon_from_power(p)), ("time", orc.shannon_per_time(p)), ("freq", orc.shannon_per_freq(p))):
+        assert np.array_equal(obj.info, g[f"sh_{nm}_info"]), nm
+        assert np.array_equal(obj.shannon_bits, g[f"sh_{nm}_bits"]), nm
+        assert obj.ref_bits == float(g[f"sh_{nm}_ref"])
+        assert np.array_equal(obj.isnr, g[f"sh_{nm}_isnr"]) and np.array_equal(obj.esnr, g[f"sh_{nm}_esnr"])
+    sig = g["sig_o3_fs1000"]
+    x = sig / np.sqrt(np.sum(sig ** 2))
+    info, ent, ref, isnr, esnr = orc.shannon_1d(x ** 2)
+    assert np.array_equal(info, g["sh1_tdr_info"]) and np.array_equal(ent, g["sh1_tdr_entropy"])
+    assert np.array_equal(isnr, g["sh1_tdr_isnr"]) and np.array_equal(esnr, g["sh1_tdr_esnr"])
+    sq = np.abs(np.fft.rfft(sig)) ** 2
+    info, ent, ref, isnr, esnr = orc.shannon_1d(sq / np.sum(sq))
+    assert np.allclose(info, g["sh1_fft_info"], rtol=1e-12, atol=0) and ref == float(g["sh1_fft_ref"])
+
+
+@pytest.mark.parametrize("tag", ["n13_fs1000", "n13_fs800", "n16_fs1000"])
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("order", [3, 12])
+def test_stft(golden, tag, dtype, order):
+    g = golden("stft.npz")
+    fs = float(tag.split("fs")[1])
+    sig = g[f"sig_{tag}_{dtype}"]
+    z, bits, t, f = orc.stft_from_sig(sig, fs, order)
+    key = f"{tag}_{dtype}_o{order}"
+    assert np.array_equal(np.array(z.shape), g[f"shape_{key}"])
+    assert np.array_equal(t, g[f"t_{key}"]) and np.array_equal(f, g[f"f_{key}"])
+    gz = g[f"z_{key}"]
+    step = 1 if gz.shape[1] == z.shape[1] else 8
+    assert z.dtype == gz.dtype
+    assert np.array_equal(z[:, ::step], gz)
+    assert np.allclose(bits[:, ::step], g[f"bits_{key}"], rtol=0, atol=1e-5 if tag.startswith("n16") else 0)
+
+
+def test_stft_2d_tukey_quarter(golden):
+    g = golden("stft.npz")
+    f, t, z = orc.stft_complex_pow2(g["sig_2d"], 1000.0, 256)
+    assert np.array_equal(f, g["f_2d"]) and np.array_equal(t, g["t_2d"])
+    assert np.array_equal(z, g["z_2d_alpha025"])
+
+
+def test_stft_short_signal_raises():
+    with pytest.raises(ValueError):
+        orc.stft_from_sig(np.zeros(1024), 1000.0, 12)
+
+
+def test_medium_digests(golden):
+    g = golden("medium_n8192.npz")
+    sig = g["sig"]
+    for order in (3, 12):
+        rows = g[f"rows_o{order}"]
+        f, _, cwt = orc.cwt_fft(order, sig, 1000.0)
+        assert np.array_equal(f, g[f"f_o{order}"])
+        assert relmax(cwt[rows], g[f"cwt_rows_o{order}"]) < 1e-13
+        p = np.abs(cwt) ** 2
+        assert np.allclose(p.sum(axis=1), g[f"cwt_psum_band_o{order}"], rtol=1e-12)
+        assert np.allclose(p.sum(axis=0), g[f"cwt_psum_time_o{order}"], rtol=1e-11)
+        assert np.isclose(np.sum(orc.shannon_from_power(p).shannon_bits), float(g[f"cwt_entropy_bits_o{order}"]), rtol=1e-12)
+        _, _, stx = orc.stx_fft(order, sig, 1000.0)
+        assert relmax(stx[rows], g[f"stx_rows_o{order}"]) < 1e-13
+        assert np.isclose((np.abs(stx) ** 2).max(), float(g[f"stx_pmax_o{order}"]), rtol=1e-12)
+        c, _, _, fc = orc.cwt_chirp_fft(sig, 1000.0, order)
+        assert np.array_equal(fc, g[f"chirp_f_o{order}"])
+        assert relmax(c[g[f"chirp_rowsel_o{order}"]], g[f"chirp_rows_o{order}"]) < 1e-10
