@@ -115,6 +115,23 @@ int qi_plan_set_stx_bands(qi_plan* plan, int32_t n_bands, const int64_t* shift_i
 
 int64_t qi_plan_bands(const qi_plan* plan, int which /* qi_bank, or 2 for the STX table */);
 
+/* ---- measurement ------------------------------------------------------------------- */
+/* Stages of one transform call, timed with HIP events on the caller's stream when profiling is on
+ * (bench.py's roofline leg; off by default, two event records per stage launch when on). */
+typedef enum {
+  QI_STAGE_FORWARD = 0,  /* pack + forward FFT of the records                                  */
+  QI_STAGE_MULTIPLY = 1, /* spectrum x atom bank, or shifted spectrum x Gaussian (hipFFT engine) */
+  QI_STAGE_INVERSE = 2,  /* batched inverse FFT (hipFFT engine)                                  */
+  QI_STAGE_EPILOGUE = 3, /* crop / power / entropy epilogue (hipFFT engine)                      */
+  QI_STAGE_PASS1 = 4,    /* native engine: fused multiply + first FFT pass                       */
+  QI_STAGE_PASS2 = 5,    /* native engine: second FFT pass + fused epilogue                      */
+  QI_STAGE_COUNT = 6
+} qi_stage;
+int qi_plan_profile(qi_plan* plan, int enable); /* enabling or disabling also clears the counters */
+/* Sum of elapsed milliseconds and number of launches per stage since the last read; waits for the
+ * recorded events.  Arrays of QI_STAGE_COUNT entries. */
+int qi_plan_profile_read(qi_plan* plan, double* stage_ms, int64_t* stage_launches, int32_t n_stages);
+
 /* ---- transforms --------------------------------------------------------------------- */
 /* styx_cwt.cwt_complex_any_scale_pow2 (styx_cwt.py:147-198, cwt_type="fft") when bank = QI_BANK_STYX;
  * cwt_atoms.cwt_chirp_complex (cwt_atoms.py:343-444, cwt_type="fft") when bank = QI_BANK_ATOMS.

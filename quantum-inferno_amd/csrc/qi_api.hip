@@ -115,6 +115,67 @@ int fft_r2c<double>(FftCache& fc, double* in, double2* out, int64_t len, int64_t
   return QI_OK;
 }
 
+// ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----
+struct Profiler {
+  static constexpr int kStages = 6;
+  bool on = false;
+  struct Span {
+    hipEvent_t a, b;
+    int stage;
+  };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t cur = nullptr;
+
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  void begin(hipStream_t st) {
+    if (!on) return;
+    cur = get();
+    if (cur) (void)hipEventRecord(cur, st);
+  }
+  void end(int stage, hipStream_t st) {
+    if (!on || !cur) return;
+    hipEvent_t b = get();
+    if (b) {
+      (void)hipEventRecord(b, st);
+      spans.push_back({cur, b, stage});
+    }
+    cur = nullptr;
+  }
+  void read(double* ms, int64_t* count) {
+    for (int i = 0; i < kStages; ++i) {
+      ms[i] = 0.0;
+      count[i] = 0;
+    }
+    for (auto& s : spans) {
+      float t = 0.f;
+      if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+        ms[s.stage] += t;
+        count[s.stage] += 1;
+      }
+      pool.push_back(s.a);
+      pool.push_back(s.b);
+    }
+    spans.clear();
+  }
+  void clear() {
+    double ms[kStages];
+    int64_t c[kStages];
+    read(ms, c);
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+};
+
 static std::mutex g_stft_mu;
 static std::map<int, FftCache> g_stft_fft;  // per device
 
@@ -134,6 +195,7 @@ struct qi_plan {
   char* ws = nullptr;
   size_t ws_bytes = 0;
   FftCache fft;
+  Profiler prof;
 };
 
 namespace {
@@ -220,16 +282,23 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
 
   for (int64_t c0 = 0; c0 < C; c0 += tl.Ct) {
     const int64_t ct = (C - c0 < tl.Ct) ? C - c0 : tl.Ct;
+    p->prof.begin(st);
     QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, L, st));
     QI_TRY(fft_c2c<T>(p->fft, X, L, ct, HIPFFT_FORWARD, st));
+    p->prof.end(QI_STAGE_FORWARD, st);
     int64_t tb = 0;
     for (int64_t j0 = 0; j0 < B; j0 += tl.Bt, ++tb) {
       const int64_t bt = (B - j0 < tl.Bt) ? B - j0 : tl.Bt;
+      p->prof.begin(st);
       if (kind == Kind::Stockwell)
         QI_TRY(launch_stx_window<T>(X, Y, ct, bt, n, p->d_stx_idx + j0, p->d_stx_coef + j0, st));
       else
         QI_TRY(launch_mul_bank<T>(X, H + j0 * L, Y, ct, bt, L, st));
+      p->prof.end(QI_STAGE_MULTIPLY, st);
+      p->prof.begin(st);
       QI_TRY(fft_c2c<T>(p->fft, Y, L, ct * bt, HIPFFT_BACKWARD, st));
+      p->prof.end(QI_STAGE_INVERSE, st);
+      p->prof.begin(st);
       EpiArgs<T> a{};
       a.Y = Y;
       a.L = L;
@@ -249,6 +318,7 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
       a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       QI_TRY(launch_epilogue<T>(a, st));
+      p->prof.end(QI_STAGE_EPILOGUE, st);
     }
     if (want_band || want_stat)
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
@@ -352,6 +422,7 @@ int qi_plan_destroy(qi_plan* p) {
   DeviceGuard g(p->d.device);
   (void)hipDeviceSynchronize();
   p->fft.clear();
+  p->prof.clear();
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);
@@ -458,6 +529,24 @@ int64_t qi_plan_bands(const qi_plan* p, int which) {
   if (!p) return 0;
   if (which == QI_BANK_STYX || which == QI_BANK_ATOMS) return p->nb[which];
   return which == 2 ? p->nb_stx : 0;
+}
+
+int qi_plan_profile(qi_plan* p, int enable) {
+  QI_REQUIRE(p, "null plan");
+  DeviceGuard g(p->d.device);
+  double ms[Profiler::kStages];
+  int64_t c[Profiler::kStages];
+  p->prof.read(ms, c);
+  p->prof.on = enable != 0;
+  return QI_OK;
+}
+
+int qi_plan_profile_read(qi_plan* p, double* stage_ms, int64_t* stage_launches, int32_t n_stages) {
+  QI_REQUIRE(p && stage_ms && stage_launches, "null argument");
+  QI_REQUIRE(n_stages == QI_STAGE_COUNT, "n_stages must be %d", (int)QI_STAGE_COUNT);
+  DeviceGuard g(p->d.device);
+  p->prof.read(stage_ms, stage_launches);
+  return QI_OK;
 }
 
 int qi_cwt(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* out, qi_stream stream) {

@@ -186,7 +186,19 @@ class TfrPlan:
         return f_hz
 
     # -- transforms ---------------------------------------------------------------------------
-    def _run(self, which, sig, coef, bits, reductions, power_scale, eps):
+    # -- measurement --------------------------------------------------------------------------
+    def profile(self, enable=True):
+        """Time every stage launch with HIP events on the current stream (qi_plan_profile)."""
+        _lib.check(self._lib.qi_plan_profile(self._handle, 1 if enable else 0))
+
+    def profile_read(self):
+        """{stage name: (total ms, launches)} since the last read (qi_plan_profile_read)."""
+        ms = (C.c_double * len(_lib.STAGES))()
+        cnt = (C.c_int64 * len(_lib.STAGES))()
+        _lib.check(self._lib.qi_plan_profile_read(self._handle, ms, cnt, len(_lib.STAGES)))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.STAGES)}
+
+    def _run(self, which, sig, coef, bits, reductions, power_scale, eps, out=None):
         if sig.dtype != self.rdtype or not sig.is_cuda or sig.device != self.device:
             sig = sig.to(device=self.device, dtype=self.rdtype)
         sig = sig.contiguous()
@@ -198,15 +210,20 @@ class TfrPlan:
             raise _lib.QiError("band table not set on this plan")
         n_b = len(f_hz)
         dev = self.device
-        res = TfrResult(frequency_hz=f_hz, power_scale=power_scale)
-        if coef:
-            res.coef = torch.empty((n_ch, n_b, self.n), dtype=_complex_of(self.rdtype), device=dev)
-        if bits:
-            res.bits = torch.empty((n_ch, n_b, self.n), dtype=self.rdtype, device=dev)
-        if reductions:
-            res.power_band = torch.empty((n_ch, n_b), dtype=torch.float64, device=dev)
-            res.power_time = torch.empty((n_ch, self.n), dtype=self.rdtype, device=dev)
-            res.stats = torch.empty((n_ch, 4), dtype=torch.float64, device=dev)
+        if out is not None:  # reuse the buffers of an earlier call of the same shape
+            res = out
+            if (res.coef is not None and res.coef.shape[0] != n_ch) or (res.stats is not None and res.stats.shape[0] != n_ch):
+                raise ValueError("out= buffers were made for another channel count")
+        else:
+            res = TfrResult(frequency_hz=f_hz, power_scale=power_scale)
+            if coef:
+                res.coef = torch.empty((n_ch, n_b, self.n), dtype=_complex_of(self.rdtype), device=dev)
+            if bits:
+                res.bits = torch.empty((n_ch, n_b, self.n), dtype=self.rdtype, device=dev)
+            if reductions:
+                res.power_band = torch.empty((n_ch, n_b), dtype=torch.float64, device=dev)
+                res.power_time = torch.empty((n_ch, self.n), dtype=self.rdtype, device=dev)
+                res.stats = torch.empty((n_ch, 4), dtype=torch.float64, device=dev)
         out = _lib.TfrOut(
             coef=_lib.ptr(res.coef),
             bits=_lib.ptr(res.bits),
@@ -224,14 +241,14 @@ class TfrPlan:
         _lib.check(rc)
         return res
 
-    def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
-        return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps)
+    def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
+        return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps, out)
 
-    def cwt_atoms(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
-        return self._run(_lib.QI_BANK_ATOMS, sig, coef, bits, reductions, power_scale, eps)
+    def cwt_atoms(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
+        return self._run(_lib.QI_BANK_ATOMS, sig, coef, bits, reductions, power_scale, eps, out)
 
-    def stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0):
-        return self._run(_lib.QI_TABLE_STX, sig, coef, bits, reductions, power_scale, eps)
+    def stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
+        return self._run(_lib.QI_TABLE_STX, sig, coef, bits, reductions, power_scale, eps, out)
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
