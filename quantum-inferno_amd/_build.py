@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libqi_tfr.so")
-SOURCES = ["qi_api.hip", "qi_kernels.hip"]
+SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip"]
 ARCH = "gfx950"
 
 

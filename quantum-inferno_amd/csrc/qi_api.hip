@@ -7,7 +7,10 @@
 #include <tuple>
 #include <vector>
 
+#include <cstdlib>
+
 #include "qi_common.hpp"
+#include "qi_native.hpp"
 
 namespace qi {
 
@@ -196,6 +199,24 @@ struct qi_plan {
   size_t ws_bytes = 0;
   FftCache fft;
   Profiler prof;
+  // native engine: per transform kind (0 styx bank, 1 atoms bank, 2 Stockwell) the band descriptors
+  struct NativeTable {
+    bool ready = false;
+    int64_t Lf = 0;
+    int32_t nbands = 0, ngen = 0;
+    native::BandDesc* d_bands = nullptr;
+    int32_t* d_gen_list = nullptr;
+    void* Hc = nullptr;
+    void* Hfull = nullptr;
+    void release() {
+      if (d_bands) (void)hipFree(d_bands);
+      if (d_gen_list) (void)hipFree(d_gen_list);
+      if (Hc) (void)hipFree(Hc);
+      if (Hfull) (void)hipFree(Hfull);
+      *this = NativeTable();
+    }
+  } nat[3];
+  int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
 };
 
 namespace {
@@ -329,6 +350,202 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
   return QI_OK;
 }
 
+bool native_len_ok(int64_t Lf) { return Lf == (1ll << 20) || Lf == (1ll << 21); }
+
+// does this plan run transform `kind` (0 styx bank, 1 atoms bank, 2 Stockwell) on the native engine?
+bool native_wanted(const qi_plan* p, int kind) {
+  if (p->d.engine == QI_ENGINE_HIPFFT || p->d.dtype != QI_F32) return false;
+  const int64_t Lf = kind == 0 ? p->L : p->n;
+  return is_pow2(p->n) && native_len_ok(Lf);
+}
+
+int upload_native_table(qi_plan* p, int kind, int64_t Lf, const std::vector<native::BandDesc>& bands) {
+  auto& t = p->nat[kind];
+  std::vector<int32_t> gen;
+  for (size_t j = 0; j < bands.size(); ++j)
+    if (bands[j].mode == 1) gen.push_back((int32_t)j);
+  QI_HIP(hipMalloc((void**)&t.d_bands, bands.size() * sizeof(native::BandDesc)));
+  QI_HIP(hipMemcpy(t.d_bands, bands.data(), bands.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
+  if (!gen.empty()) {
+    QI_HIP(hipMalloc((void**)&t.d_gen_list, gen.size() * sizeof(int32_t)));
+    QI_HIP(hipMemcpy(t.d_gen_list, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  t.Lf = Lf;
+  t.nbands = (int32_t)bands.size();
+  t.ngen = (int32_t)gen.size();
+  t.ready = true;
+  return QI_OK;
+}
+
+// Native bank: analyse the support of every atom spectrum, keep a compact window for the narrow ones and
+// the full row for the wide ones (two sweeps over the float64 rows so that only one chunk is resident).
+template <typename T>
+int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipStream_t st) {
+  const int64_t n = p->n;
+  const int circular = bank == QI_BANK_ATOMS;
+  const int64_t L = circular ? n : p->L;
+  const size_t row64 = (size_t)L * sizeof(double2);
+  int64_t chunk = (int64_t)((p->ws_bytes - 4096) / row64);
+  if (chunk < 1) {
+    set_error("workspace too small to build one bank row (%zu bytes needed)", row64);
+    return QI_ERR_NOMEM;
+  }
+  if (chunk > B) chunk = B;
+  double2* rows = reinterpret_cast<double2*>(p->ws);
+  double* d_sup = nullptr;
+  QI_HIP(hipMalloc((void**)&d_sup, (size_t)B * 3 * sizeof(double)));
+  const double thr2 = std::ldexp(1.0, -60);  // |H| below 2^-30 of the row maximum is dropped
+  int rc = QI_OK;
+  for (int32_t j0 = 0; j0 < B && rc == QI_OK; j0 += (int32_t)chunk) {
+    const int nbk = (B - j0 < chunk) ? B - j0 : (int)chunk;
+    rc = launch_bank_rows(rows, n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0, nbk, st);
+    if (rc == QI_OK) rc = fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st);
+    if (rc == QI_OK) rc = native::launch_band_support(rows, L, nbk, thr2, d_sup + (size_t)j0 * 3, st);
+  }
+  std::vector<double> sup((size_t)B * 3);
+  if (rc == QI_OK && (hipStreamSynchronize(st) != hipSuccess ||
+                      hipMemcpy(sup.data(), d_sup, sup.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) {
+    set_error("support analysis failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = QI_ERR_HIP;
+  }
+  (void)hipFree(d_sup);
+  QI_TRY(rc);
+  std::vector<native::BandDesc> bands(B);
+  int64_t compact = 0;
+  int32_t ngen = 0;
+  for (int32_t j = 0; j < B; ++j) {
+    native::BandDesc& d = bands[j];
+    memset(&d, 0, sizeof(d));
+    const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
+    const int64_t len = hi >= lo ? hi - lo + 1 : 0;
+    if (len > 0 && len <= p->native_kmax) {
+      d.mode = 0;
+      d.k_lo = (int32_t)lo;
+      d.k_len = (int32_t)len;
+      d.src_off = compact;
+      compact += len;
+    } else {
+      d.mode = 1;
+      d.gen_slot = ngen++;
+    }
+  }
+  auto& t = p->nat[bank];
+  t.release();
+  if (compact > 0) QI_HIP(hipMalloc(&t.Hc, (size_t)compact * sizeof(cplx<T>)));
+  if (ngen > 0) QI_HIP(hipMalloc(&t.Hfull, (size_t)ngen * L * sizeof(cplx<T>)));
+  for (int32_t j0 = 0; j0 < B; j0 += (int32_t)chunk) {
+    const int nbk = (B - j0 < chunk) ? B - j0 : (int)chunk;
+    QI_TRY(launch_bank_rows(rows, n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0, nbk, st));
+    QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
+    for (int jj = 0; jj < nbk; ++jj) {
+      const native::BandDesc& d = bands[j0 + jj];
+      if (d.mode == 0)
+        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
+                                              d.k_len, circular, 1.0 / (double)L, st));
+      else
+        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
+                                              static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.gen_slot * L, 0, L, circular,
+                                              1.0 / (double)L, st));
+    }
+  }
+  return upload_native_table(p, bank, L, bands);
+}
+
+// One transform on the native engine: forward FFT of the records (hipFFT), pass 1 for the wide bands,
+// pass 2 with the fused epilogue for every band, fixed-order finalisation of the reductions.
+template <typename T>
+int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
+  const auto& t = p->nat[kind];
+  const int64_t n = p->n, Lf = t.Lf, B = t.nbands;
+  const T* sig = static_cast<const T*>(sig_v);
+  const int G = native::pass2_rows_per_group();
+  const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
+  int nchunk = (int)ceil_div(512, nblk * C);
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > B) nchunk = (int)B;
+  const int bpc = (int)ceil_div(B, nchunk);
+  nchunk = (int)ceil_div(B, bpc);
+  const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
+  const bool want_time = out->power_time != nullptr;
+  const bool time_via_part = want_time && nchunk > 1;
+  // scratch regions, each [Ct][...] without per-channel padding
+  const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
+  const size_t e_imd = (size_t)t.ngen * Lf * sizeof(cplx<T>);
+  const size_t e_pb = (size_t)B * nblk * 8;
+  const size_t e_ps = (size_t)nchunk * nblk * 24;
+  const size_t e_tp = time_via_part ? (size_t)nchunk * n * sizeof(T) : 0;
+  const size_t per_chan = e_x + e_imd + e_pb + e_ps + e_tp;
+  if (p->ws_bytes < per_chan + 2048) {
+    set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
+              per_chan + 2048);
+    return QI_ERR_NOMEM;
+  }
+  int64_t Ct = (int64_t)((p->ws_bytes - 2048) / per_chan);
+  if (Ct > C) Ct = C;
+  char* w = p->ws;
+  cplx<T>* X = reinterpret_cast<cplx<T>*>(w);
+  w += align_up(e_x * Ct);
+  cplx<T>* imd = reinterpret_cast<cplx<T>*>(w);
+  w += align_up(e_imd * Ct);
+  double* part_band = reinterpret_cast<double*>(w);
+  w += align_up(e_pb * Ct);
+  double* part_stat = reinterpret_cast<double*>(w);
+  w += align_up(e_ps * Ct);
+  T* time_part = reinterpret_cast<T*>(w);
+
+  for (int64_t c0 = 0; c0 < C; c0 += Ct) {
+    const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
+    p->prof.begin(st);
+    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
+    QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    p->prof.end(QI_STAGE_FORWARD, st);
+    native::RowArgs<T> a{};
+    a.Lf = Lf;
+    a.n = n;
+    a.N1 = N1;
+    a.N2 = native::kN2;
+    a.off = kind == 0 ? (n - 1) / 2 : (kind == 1 ? n / 2 : 0);
+    a.wrap = kind == 0 ? 0 : 1;
+    a.nbands = (int32_t)B;
+    a.bands = t.d_bands;
+    a.gen_list = t.d_gen_list;
+    a.ngen = t.ngen;
+    a.ngen_launch = t.ngen;
+    a.X = X;
+    a.Hc = static_cast<const cplx<T>*>(t.Hc);
+    a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
+    a.imd = imd;
+    a.inv_len = (T)(1.0 / (double)Lf);
+    a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+    a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+    a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+    a.part_band = want_band ? part_band : nullptr;
+    a.part_stat = want_stat ? part_stat : nullptr;
+    a.nblk = nblk;
+    a.bands_per_chunk = bpc;
+    a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+    a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+    if (t.ngen > 0) {
+      p->prof.begin(st);
+      QI_TRY(native::launch_pass1<T>(a, kind == 2, ct, st));
+      p->prof.end(QI_STAGE_PASS1, st);
+    }
+    p->prof.begin(st);
+    QI_TRY(native::launch_pass2<T>(a, kind == 2, nchunk, ct, st));
+    p->prof.end(QI_STAGE_PASS2, st);
+    p->prof.begin(st);
+    if (time_via_part)
+      QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, nchunk, st));
+    if (want_band || want_stat)
+      QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
+                             want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
+                             want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nblk,
+                             (int64_t)nchunk * nblk, st));
+    p->prof.end(QI_STAGE_EPILOGUE, st);
+  }
+  return QI_OK;
+}
+
 template <typename T>
 int build_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipStream_t st) {
   const int64_t n = p->n;
@@ -391,8 +608,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   QI_REQUIRE(desc->n >= 2 && desc->n <= (1ll << 28), "n = %lld out of range", (long long)desc->n);
   QI_REQUIRE(desc->dtype == QI_F32 || desc->dtype == QI_F64, "bad dtype %d", desc->dtype);
   QI_REQUIRE(desc->engine >= QI_ENGINE_AUTO && desc->engine <= QI_ENGINE_NATIVE, "bad engine %d", desc->engine);
-  if (desc->engine == QI_ENGINE_NATIVE) {
-    set_error("native engine not available in this build");
+  if (desc->engine == QI_ENGINE_NATIVE && !(desc->dtype == QI_F32 && is_pow2(desc->n) &&
+                                            (native_len_ok(desc->n) || native_len_ok(2 * desc->n)))) {
+    set_error("native engine: float32 records of 2^19, 2^20 or 2^21 samples only (got n = %lld, dtype %d)",
+              (long long)desc->n, desc->dtype);
     return QI_ERR_UNSUPPORTED;
   }
   DeviceGuard g(desc->device);
@@ -407,6 +626,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   // scipy.signal.fftconvolve pads to next_fast_len(2n-1) (= 2n when n = 2^k); any L >= 2n-1 gives the
   // same linear correlation, so other n use the next power of two.
   p->L = is_pow2(desc->n) ? 2 * desc->n : next_pow2(2 * desc->n - 1);
+  if (const char* e = getenv("QI_NATIVE_KMAX")) {
+    const long v = atol(e);
+    if (v >= 0) p->native_kmax = v;
+  }
   p->ws_bytes = desc->workspace_bytes > 0 ? (size_t)desc->workspace_bytes : ((size_t)2 << 30);
   if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {
     set_error("hipMalloc of %zu workspace bytes failed", p->ws_bytes);
@@ -423,6 +646,7 @@ int qi_plan_destroy(qi_plan* p) {
   (void)hipDeviceSynchronize();
   p->fft.clear();
   p->prof.clear();
+  for (auto& t : p->nat) t.release();
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);
@@ -447,7 +671,15 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     p->bank[bank] = nullptr;
     p->nb[bank] = 0;
   }
-  QI_HIP(hipMalloc(&p->bank[bank], (size_t)B * L * esz));
+  const bool use_native = native_wanted(p, bank);
+  if (!use_native) {
+    if (p->d.engine == QI_ENGINE_NATIVE) {
+      set_error("native engine does not support this bank at n = %lld", (long long)p->n);
+      return QI_ERR_UNSUPPORTED;
+    }
+    QI_HIP(hipMalloc(&p->bank[bank], (size_t)B * L * esz));
+  }
+  p->nat[bank].release();
   double* d_par = nullptr;
   QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
   std::vector<double> host((size_t)4 * B);
@@ -460,8 +692,12 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     set_error("hipMemcpy of band parameters failed");
     rc = QI_ERR_HIP;
   }
-  if (rc == QI_OK)
-    rc = p->d.dtype == QI_F64 ? build_bank<double>(p, bank, B, d_par, st) : build_bank<float>(p, bank, B, d_par, st);
+  if (rc == QI_OK) {
+    if (use_native)
+      rc = build_native_bank<float>(p, bank, B, d_par, st);
+    else
+      rc = p->d.dtype == QI_F64 ? build_bank<double>(p, bank, B, d_par, st) : build_bank<float>(p, bank, B, d_par, st);
+  }
   if (rc == QI_OK && hipStreamSynchronize(st) != hipSuccess) {
     set_error("bank build failed on the device: %s", hipGetErrorString(hipGetLastError()));
     rc = QI_ERR_HIP;
@@ -522,6 +758,31 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
   QI_HIP(hipMemcpy(p->d_stx_idx, shift_index, B * sizeof(int64_t), hipMemcpyHostToDevice));
   QI_HIP(hipMemcpy(p->d_stx_coef, coef.data(), B * sizeof(double), hipMemcpyHostToDevice));
   p->nb_stx = B;
+  p->nat[2].release();
+  if (native_wanted(p, 2)) {
+    // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef
+    std::vector<native::BandDesc> bands(B);
+    int32_t ngen = 0;
+    for (int32_t j = 0; j < B; ++j) {
+      native::BandDesc& d = bands[j];
+      memset(&d, 0, sizeof(d));
+      d.shift = shift_index[j];
+      d.coef = coef[j];
+      const double kh = std::floor(std::sqrt(30.0) / coef[j]);
+      if (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n) {
+        d.mode = 0;
+        d.k_lo = -(int32_t)kh;
+        d.k_len = 2 * (int32_t)kh + 1;
+      } else {
+        d.mode = 1;
+        d.gen_slot = ngen++;
+      }
+    }
+    QI_TRY(upload_native_table(p, 2, p->n, bands));
+  } else if (p->d.engine == QI_ENGINE_NATIVE) {
+    set_error("native engine does not support the Stockwell transform at n = %lld", (long long)p->n);
+    return QI_ERR_UNSUPPORTED;
+  }
   return QI_OK;
 }
 
@@ -555,6 +816,7 @@ int qi_cwt(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* o
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
   const Kind k = bank == QI_BANK_STYX ? Kind::Linear : Kind::Circular;
+  if (p->nat[bank].ready) return run_native<float>(p, bank, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, k, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, k, sig, C, out, (hipStream_t)stream);
 }
@@ -563,6 +825,7 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
   QI_REQUIRE(p && sig && out, "null argument");
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
+  if (p->nat[2].ready) return run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
 }

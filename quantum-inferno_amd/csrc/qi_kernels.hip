@@ -2,35 +2,11 @@
 // spectrum multiply, Stockwell shift x Gaussian, crop / power / entropy epilogue, STFT framing,
 // tfr_info reductions.  Wave = 64 lanes everywhere.
 #include "qi_common.hpp"
+#include "qi_device.hpp"
 
 namespace qi {
 
 namespace {
-
-constexpr int kWave = 64;
-
-template <typename T>
-__device__ inline T wave_sum(T v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-  return v;
-}
-template <typename T>
-__device__ inline T wave_max(T v) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) {
-    T w = __shfl_down(v, o, kWave);
-    v = w > v ? w : v;
-  }
-  return v;
-}
-
-__device__ inline float log2_t(float v) { return log2f(v); }
-__device__ inline double log2_t(double v) { return log2(v); }
-__device__ inline float sqrt_t(float v) { return sqrtf(v); }
-__device__ inline double sqrt_t(double v) { return sqrt(v); }
-__device__ inline float exp2_t(float v) { return exp2f(v); }
-__device__ inline double exp2_t(double v) { return exp2(v); }
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -1,0 +1,510 @@
+// Native gfx950 FFT passes for the inverse transforms of the TFR panels.
+//
+// An inverse FFT of length Lf = N1 * N2 (N2 = 1024) is evaluated as out[t1 + N1 t2] =
+//   sum_k2 A[t1][k2] W_N2^(k2 t2),   A[t1][k2] = sum_{k == k2 mod N2} Y[k] W_Lf^(k t1).
+// One workgroup owns G consecutive t1 (so every store is a run of G consecutive time samples),
+// holds the G rows of N2 points in LDS, transforms them with two register radix-32 steps and one
+// LDS exchange, and applies the crop / power / entropy epilogue from registers.
+//  * A band whose spectrum product Y has a short support (a Gaussian atom far from DC) gets A
+//    straight from the spectrum: "pruned" loader, no intermediate in HBM at all.
+//  * A wide band goes through pass 1 (the same row kernel over k1 for G1 consecutive k2) which writes
+//    A once to an intermediate [k2][t1]; pass 2 reads it back transposed through LDS.
+// Wave = 64 lanes; no MFMA (there is no dense contraction on this path).
+#include <utility>
+
+#include "qi_common.hpp"
+#include "qi_device.hpp"
+#include "qi_native.hpp"
+
+namespace qi {
+namespace native {
+
+namespace {
+
+// cos / sin of 2 pi k / 64, exact at the quadrant points so that trivial twiddles fold away
+constexpr double kCos64[33] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867,
+                               0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476,
+                               0.6343932841636455, 0.5555702330196023, 0.4713967368259978, 0.38268343236508984,
+                               0.29028467725446233, 0.19509032201612833, 0.09801714032956077, 0.0,
+                               -0.09801714032956065, -0.1950903220161282, -0.29028467725446216, -0.3826834323650897,
+                               -0.4713967368259977, -0.555570233019602, -0.6343932841636454, -0.7071067811865475,
+                               -0.773010453362737, -0.8314696123025453, -0.8819212643483549, -0.9238795325112867,
+                               -0.9569403357322088, -0.9807852804032304, -0.9951847266721968, -1.0};
+constexpr double kSin64[33] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898,
+                               0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865475,
+                               0.773010453362737, 0.8314696123025452, 0.8819212643483549, 0.9238795325112867,
+                               0.9569403357322089, 0.9807852804032304, 0.9951847266721968, 1.0, 0.9951847266721969,
+                               0.9807852804032304, 0.9569403357322089, 0.9238795325112867, 0.881921264348355,
+                               0.8314696123025455, 0.7730104533627371, 0.7071067811865476, 0.6343932841636455,
+                               0.5555702330196022, 0.47139673682599786, 0.3826834323650899, 0.2902846772544624,
+                               0.1950903220161286, 0.09801714032956083, 0.0};
+
+// v * W_64^(DIR * K), K in [0, 32)
+template <typename T, int K, int DIR>
+__device__ __forceinline__ cplx<T> mul_tw64(cplx<T> v) {
+  static_assert(K >= 0 && K < 32, "twiddle exponent");
+  if constexpr (K == 0) {
+    return v;
+  } else if constexpr (K == 16) {
+    return DIR > 0 ? mk<T>(-v.y, v.x) : mk<T>(v.y, -v.x);
+  } else {
+    constexpr T c = (T)kCos64[K];
+    constexpr T s = (T)(DIR * kSin64[K]);
+    return mk<T>(v.x * c - v.y * s, v.x * s + v.y * c);
+  }
+}
+
+constexpr int brev(int x, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+  return r;
+}
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// one radix-2 decimation-in-frequency butterfly of stage S (half span) on register array v[R]
+template <typename T, int R, int S, int DIR, int I>
+__device__ __forceinline__ void bfly(cplx<T> (&v)[R]) {
+  constexpr int i = I % S;
+  constexpr int p = (I / S) * 2 * S;
+  const cplx<T> a = v[p + i], b = v[p + i + S];
+  v[p + i] = mk<T>(a.x + b.x, a.y + b.y);
+  v[p + i + S] = mul_tw64<T, i*(32 / S), DIR>(mk<T>(a.x - b.x, a.y - b.y));
+}
+template <typename T, int R, int S, int DIR, int... Is>
+__device__ __forceinline__ void stage(cplx<T> (&v)[R], std::integer_sequence<int, Is...>) {
+  (bfly<T, R, S, DIR, Is>(v), ...);
+}
+// In-register FFT of R points (R = 2^m <= 64); output index d ends up in v[brev(d)].
+template <typename T, int R, int DIR, int S = R / 2>
+__device__ __forceinline__ void fft_reg(cplx<T> (&v)[R]) {
+  stage<T, R, S, DIR>(v, std::make_integer_sequence<int, R / 2>{});
+  if constexpr (S > 1) fft_reg<T, R, DIR, S / 2>(v);
+}
+
+// exp(DIR * 2 pi i m / len) for an exact integer phase, single precision seeds
+__device__ __forceinline__ void unit_root(int64_t m, int64_t len, int dir, double* c, double* s) {
+  float sf, cf;
+  sincospif((float)(2.0 * (double)m / (double)len), &sf, &cf);
+  *c = cf;
+  *s = dir > 0 ? sf : -sf;
+}
+__device__ __forceinline__ int64_t pmod(int64_t a, int64_t m) {
+  int64_t r = a % m;
+  return r < 0 ? r + m : r;
+}
+
+template <typename T, int R2_, int G_, bool DFAST_>
+struct Cfg {
+  static constexpr int R1 = 32, R2 = R2_, NR = 32 * R2_, G = G_, TH = 32 * G_;
+  static constexpr bool DFAST = DFAST_;
+  static constexpr int SR = NR + 1;      // row stride of the natural-order image A[g][k]
+  static constexpr int SA = 32 * G_ + 1; // a-stride of the exchange image E[a][...]
+  static constexpr int BUF = (G_ * SR > R2_ * SA) ? G_ * SR : R2_ * SA;
+  static constexpr int NF1 = R2_ / 32;   // step-1 FFTs per thread
+  static constexpr size_t LDS_BYTES = ((size_t)BUF + NR) * sizeof(cplx<T>) + 256;
+};
+
+// ---- loaders: fill A[g][k] (row stride SR) for the G rows of this workgroup ---------------------------------------
+// pruned: A[g][k mod 1024] = sum_k Y[k] W_Lf^(k (t1_0 + g))
+template <typename T, class C, bool STX>
+__device__ __forceinline__ void load_pruned(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd, int64_t ch, int64_t t1_0) {
+  const int tid = threadIdx.x;
+  const int64_t k_end = (int64_t)bd.k_lo + bd.k_len;
+  for (int slot = tid; slot < C::NR; slot += C::TH) {
+    cplx<T> acc[C::G];
+#pragma unroll
+    for (int g = 0; g < C::G; ++g) acc[g] = mk<T>(T(0), T(0));
+    for (int64_t k = bd.k_lo + pmod(slot - bd.k_lo, C::NR); k < k_end; k += C::NR) {
+      cplx<T> y;
+      if constexpr (STX) {
+        const cplx<T> x = a.X[ch * a.Lf + pmod(k + bd.shift, a.Lf)];
+        const T e = (T)bd.coef * (T)k;
+        const T w = exp2_t(-e * e) * a.inv_len;
+        y = mk<T>(x.x * w, x.y * w);
+      } else {
+        y = cmul(a.X[ch * a.Lf + k], a.Hc[bd.src_off + (k - bd.k_lo)]);
+      }
+      double wr, wi, sr, si;
+      unit_root(pmod(k * t1_0, a.Lf), a.Lf, 1, &wr, &wi);
+      unit_root(pmod(k, a.Lf), a.Lf, 1, &sr, &si);
+#pragma unroll
+      for (int g = 0; g < C::G; ++g) {
+        const T cr = (T)wr, ci = (T)wi;
+        acc[g].x += y.x * cr - y.y * ci;
+        acc[g].y += y.x * ci + y.y * cr;
+        const double nr = wr * sr - wi * si;
+        wi = wr * si + wi * sr;
+        wr = nr;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < C::G; ++g) A[g * C::SR + slot] = acc[g];
+  }
+}
+
+// general pass 2: A[g][k2] = imd[k2][t1_0 + g]  (G consecutive elements per k2, transposed through LDS)
+template <typename T, class C>
+__device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* imd, int64_t n1, int64_t t1_0) {
+  const int tid = threadIdx.x;
+  const int g = tid % C::G;
+  for (int k2 = tid / C::G; k2 < C::NR; k2 += C::TH / C::G) A[g * C::SR + k2] = imd[(int64_t)k2 * n1 + t1_0 + g];
+}
+
+// general pass 1: A[r][k1] = Y[k2_0 + r + N2 k1]
+template <typename T, class C, bool STX>
+__device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd, int64_t ch, int64_t k2_0) {
+  const int tid = threadIdx.x;
+  const int r = tid % C::G;
+  const cplx<T>* H = STX ? nullptr : a.Hfull + (int64_t)bd.gen_slot * a.Lf;
+  for (int k1 = tid / C::G; k1 < C::NR; k1 += C::TH / C::G) {
+    const int64_t k = k2_0 + r + (int64_t)a.N2 * k1;
+    cplx<T> y;
+    if constexpr (STX) {
+      const int64_t ks = (k <= (a.Lf - 1) / 2) ? k : k - a.Lf;
+      int64_t src = k + bd.shift;
+      if (src >= a.Lf) src -= a.Lf;
+      const cplx<T> x = a.X[ch * a.Lf + src];
+      const T e = (T)bd.coef * (T)ks;
+      const T w = exp2_t(-e * e) * a.inv_len;
+      y = mk<T>(x.x * w, x.y * w);
+    } else {
+      y = cmul(a.X[ch * a.Lf + k], H[k]);
+    }
+    A[r * C::SR + k1] = y;
+  }
+}
+
+// ---- the row kernel ----------------------------------------------------------------------------------------------
+// PASS = 1: rows are k2 (G consecutive), transform over k1, write imd[k2][t1] * W_Lf^(k2 t1).
+// PASS = 2: rows are t1 (G consecutive), transform over k2, epilogue into the panel.
+template <typename T, class C, int PASS, bool STX>
+__global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* tw = buf + C::BUF;  // tw[d * R2 + a] = W_NR^(a d)
+  __shared__ double s_red[2][C::TH / kWave];
+  __shared__ double s_fin[3][C::TH / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int64_t grp = blockIdx.x, ch = blockIdx.z;
+  const int64_t row0 = grp * C::G;
+
+  for (int i = tid; i < C::NR; i += C::TH) {
+    const int d = i / C::R2, aa = i % C::R2;
+    float sf, cf;
+    sincospif((float)(2 * ((aa * d) % C::NR)) / (float)C::NR, &sf, &cf);
+    tw[i] = mk<T>((T)cf, (T)sf);
+  }
+
+  // step-1 / step-2 thread coordinates
+  const int g1 = tid / 32, a1 = tid % 32;
+  const int g2 = C::DFAST ? tid / 32 : tid % C::G;
+  const int d2 = C::DFAST ? tid % 32 : tid / C::G;
+
+  T col[C::R2];
+#pragma unroll
+  for (int c = 0; c < C::R2; ++c) col[c] = T(0);
+  T mx = T(0);
+  double plogp = 0.0;
+  int64_t jb0, jb1;
+  if constexpr (PASS == 1) {
+    jb0 = blockIdx.y;
+    jb1 = jb0 + 1;
+  } else {
+    jb0 = (int64_t)blockIdx.y * a.bands_per_chunk;
+    jb1 = jb0 + a.bands_per_chunk < a.nbands ? jb0 + a.bands_per_chunk : a.nbands;
+  }
+  int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
+
+  for (int64_t jj = jb0; jj < jb1; ++jj) {
+    const BandDesc bd = PASS == 1 ? a.bands[a.gen_list[jj]] : a.bands[jj];
+    const int64_t j = PASS == 1 ? a.gen_list[jj] : jj;
+    // ---- load
+    if constexpr (PASS == 1) {
+      load_full<T, C, STX>(buf, a, bd, ch, row0);
+    } else {
+      if (bd.mode == 0)
+        load_pruned<T, C, STX>(buf, a, bd, ch, row0);
+      else
+        load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, a.N1, row0);
+    }
+    __syncthreads();
+    if (PASS == 2 && pending >= 0 && tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[pending & 1][w];
+      a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
+    }
+    // ---- step 1: R2 transforms of 32 points per row (over b), twiddle W_NR^(a d)
+    cplx<T> v[C::NF1][32];
+#pragma unroll
+    for (int q = 0; q < C::NF1; ++q) {
+      const int aa = a1 + 32 * q;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) v[q][b] = buf[g1 * C::SR + aa + C::R2 * b];
+      fft_reg<T, 32, 1>(v[q]);
+#pragma unroll
+      for (int d = 1; d < 32; ++d) v[q][brev(d, 5)] = cmul(v[q][brev(d, 5)], tw[d * C::R2 + aa]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < C::NF1; ++q) {
+      const int aa = a1 + 32 * q;
+#pragma unroll
+      for (int d = 0; d < 32; ++d)
+        buf[aa * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[q][brev(d, 5)];
+    }
+    __syncthreads();
+    // ---- step 2: 32 transforms of R2 points per row (over a)
+    cplx<T> u[C::R2];
+#pragma unroll
+    for (int aa = 0; aa < C::R2; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
+    __syncthreads();
+    fft_reg<T, C::R2, 1>(u);
+    constexpr int LB = ilog2(C::R2);
+
+    if constexpr (PASS == 1) {
+      // imd[k2][t1] = u * W_Lf^(k2 t1), t1 = d2 + 32 c
+      const int64_t k2 = row0 + g2;
+      cplx<T>* dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
+      double wr, wi, sr, si;
+      unit_root(pmod(k2 * d2, a.Lf), a.Lf, 1, &wr, &wi);
+      unit_root(pmod(k2 * 32, a.Lf), a.Lf, 1, &sr, &si);
+#pragma unroll
+      for (int c = 0; c < C::R2; ++c) {
+        const cplx<T> z = u[brev(c, LB)];
+        const T cr = (T)wr, ci = (T)wi;
+        dst[d2 + 32 * c] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
+        const double nr = wr * sr - wi * si;
+        wi = wr * si + wi * sr;
+        wr = nr;
+      }
+    } else {
+      const int64_t t1 = row0 + g2;
+      const int64_t orow = ((int64_t)ch * a.nbands + j) * a.n;
+      T rowacc = T(0);
+#pragma unroll
+      for (int c = 0; c < C::R2; ++c) {
+        const cplx<T> z = u[brev(c, LB)];
+        const int64_t t = t1 + a.N1 * (int64_t)(d2 + 32 * c);
+        int64_t tt = t - a.off;
+        bool ok = true;
+        if (a.wrap) {
+          if (tt < 0) tt += a.n;
+        } else {
+          ok = tt >= 0 && tt < a.n;
+        }
+        if (ok) {
+          if (a.coef) a.coef[orow + tt] = z;
+          const T m2 = z.x * z.x + z.y * z.y;
+          if (a.bits) a.bits[orow + tt] = log2_t(sqrt_t(m2) + a.eps);
+          const T p = a.power_scale * m2;
+          col[c] += p;
+          rowacc += p;
+          mx = p > mx ? p : mx;
+          if (p > T(0)) plogp += (double)(p * log2_t(p));
+        }
+      }
+      if (a.part_band) {
+        const double r = wave_sum((double)rowacc);
+        if (lane == 0) s_red[j & 1][wv] = r;
+        pending = j;
+      }
+    }
+  }
+
+  if constexpr (PASS == 2) {
+    __syncthreads();
+    if (pending >= 0 && tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[pending & 1][w];
+      a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
+    }
+    T tot = T(0);
+    const int64_t t1 = row0 + g2;
+#pragma unroll
+    for (int c = 0; c < C::R2; ++c) {
+      tot += col[c];
+      if (a.time_part) {
+        const int64_t t = t1 + a.N1 * (int64_t)(d2 + 32 * c);
+        int64_t tt = t - a.off;
+        bool ok = true;
+        if (a.wrap) {
+          if (tt < 0) tt += a.n;
+        } else {
+          ok = tt >= 0 && tt < a.n;
+        }
+        if (ok) a.time_part[((int64_t)ch * gridDim.y + blockIdx.y) * a.n + tt] = col[c];
+      }
+    }
+    if (a.part_stat) {
+      const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
+      if (lane == 0) {
+        s_fin[0][wv] = r0;
+        s_fin[1][wv] = r1;
+        s_fin[2][wv] = r2;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double m = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < C::TH / kWave; ++w) {
+          m = s_fin[0][w] > m ? s_fin[0][w] : m;
+          s1 += s_fin[1][w];
+          s2 += s_fin[2][w];
+        }
+        double* o = a.part_stat + (((int64_t)ch * gridDim.y + blockIdx.y) * a.nblk + grp) * 3;
+        o[0] = m;
+        o[1] = s1;
+        o[2] = s2;
+      }
+    }
+  }
+}
+
+// power_time[c][t] = sum over chunks of time_part[c][q][t]
+template <typename T>
+__global__ void k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk) {
+  const int64_t c = blockIdx.y;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    T s = T(0);
+    for (int q = 0; q < nchunk; ++q) s += part[(c * nchunk + q) * n + t];
+    out[c * n + t] = s;
+  }
+}
+
+// per band: max |F|^2 and the first / last bin at or above thr2 * max (plan-time support analysis)
+__global__ void __launch_bounds__(256) k_band_support(const double2* __restrict__ F, int64_t L, double thr2,
+                                                      double* __restrict__ out /*[nb][3]*/) {
+  __shared__ double s[256 / kWave];
+  __shared__ double s_max;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const double2* f = F + (int64_t)blockIdx.x * L;
+  double m = 0.0;
+  for (int64_t k = tid; k < L; k += 256) {
+    const double p = f[k].x * f[k].x + f[k].y * f[k].y;
+    m = p > m ? p : m;
+  }
+  m = wave_max(m);
+  if (lane == 0) s[wv] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 256 / kWave; ++w) t = s[w] > t ? s[w] : t;
+    s_max = t;
+  }
+  __syncthreads();
+  const double cut = s_max * thr2;
+  double lo = (double)L, hi = -1.0;
+  for (int64_t k = tid; k < L; k += 256) {
+    const double p = f[k].x * f[k].x + f[k].y * f[k].y;
+    if (p >= cut && p > 0.0) {
+      lo = (double)k < lo ? (double)k : lo;
+      hi = (double)k > hi ? (double)k : hi;
+    }
+  }
+  lo = -wave_max(-lo);
+  hi = wave_max(hi);
+  __shared__ double s_lo[256 / kWave], s_hi[256 / kWave];
+  if (lane == 0) {
+    s_lo[wv] = lo;
+    s_hi[wv] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 0; w < 256 / kWave; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    out[blockIdx.x * 3 + 0] = s_max;
+    out[blockIdx.x * 3 + 1] = lo;
+    out[blockIdx.x * 3 + 2] = hi;
+  }
+}
+
+// copy a window of a float64 spectrum row into working precision, scaled (and conjugated for the circular bank)
+template <typename T>
+__global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict__ dst, int64_t k_lo, int64_t count,
+                              int conj, double scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double2 v = F[k_lo + i];
+  dst[i] = mk<T>((T)(v.x * scale), (T)((conj ? -v.y : v.y) * scale));
+}
+
+}  // namespace
+
+#define QI_LAUNCH_CHECK()                                                                \
+  do {                                                                                   \
+    hipError_t e_ = hipGetLastError();                                                   \
+    if (e_ != hipSuccess) {                                                              \
+      set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return QI_ERR_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+template <typename T, class C, int PASS, bool STX>
+static int launch_rows(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  auto kern = k_rows<T, C, PASS, STX>;
+  if (!configured) {
+    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)C::LDS_BYTES));
+    configured = true;
+  }
+  kern<<<grid, C::TH, C::LDS_BYTES, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_pass1<float>(const RowArgs<float>& a, bool stx, int64_t n_channels, hipStream_t st) {
+  if (a.ngen_launch <= 0) return QI_OK;
+  if (a.N1 == 1024) {
+    using C = Cfg<float, 32, 16, true>;
+    dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
+    return stx ? launch_rows<float, C, 1, true>(a, grid, st) : launch_rows<float, C, 1, false>(a, grid, st);
+  }
+  if (a.N1 == 2048) {
+    using C = Cfg<float, 64, 8, true>;
+    dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
+    return stx ? launch_rows<float, C, 1, true>(a, grid, st) : launch_rows<float, C, 1, false>(a, grid, st);
+  }
+  set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
+  return QI_ERR_UNSUPPORTED;
+}
+
+template <>
+int launch_pass2<float>(const RowArgs<float>& a, bool stx, int nchunk, int64_t n_channels, hipStream_t st) {
+  using C = Cfg<float, 32, 16, false>;
+  dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
+  return stx ? launch_rows<float, C, 2, true>(a, grid, st) : launch_rows<float, C, 2, false>(a, grid, st);
+}
+
+int pass2_rows_per_group() { return 16; }
+
+template <typename T>
+int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st) {
+  dim3 g((unsigned)(ceil_div(n, 256) > 1024 ? 1024 : ceil_div(n, 256)), (unsigned)C);
+  k_time_reduce<T><<<g, 256, 0, st>>>(part, out, n, nchunk);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, hipStream_t);
+template int launch_time_reduce<double>(const double*, double*, int64_t, int64_t, int, hipStream_t);
+
+int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st) {
+  k_band_support<<<nb, 256, 0, st>>>(F, L, thr2, out);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <typename T>
+int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
+                       hipStream_t st) {
+  k_copy_window<T><<<(unsigned)ceil_div(count, 256), 256, 0, st>>>(F, dst, k_lo, count, conj, scale);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_copy_window<float>(const double2*, float2*, int64_t, int64_t, int, double, hipStream_t);
+template int launch_copy_window<double>(const double2*, double2*, int64_t, int64_t, int, double, hipStream_t);
+
+}  // namespace native
+}  // namespace qi

@@ -1,0 +1,57 @@
+// Interface of the native (hand-written FFT pass) engine, see qi_native.hip.
+#pragma once
+#include "qi_common.hpp"
+
+namespace qi {
+namespace native {
+
+constexpr int kN2 = 1024;  // points of the in-LDS row transform of pass 2
+
+struct BandDesc {
+  int32_t mode;      // 0: pruned (spectrum support short enough for the one-pass loader), 1: general
+  int32_t k_lo;      // first bin of the support (negative for the Stockwell window, centred on 0)
+  int32_t k_len;     // number of support bins
+  int32_t gen_slot;  // general bands: row in the intermediate / in the full-row bank
+  int64_t src_off;   // pruned Gabor bands: offset of H[k_lo] in the compact bank
+  int64_t shift;     // Stockwell: shift index idx_j
+  double coef;       // Stockwell: window coefficient (exp2(-(coef k)^2))
+};
+
+template <typename T>
+struct RowArgs {
+  int64_t Lf, n, N1, N2, off;
+  int32_t wrap;  // 1: out index (t - off) mod n (circular / Stockwell), 0: crop [off, off + n)
+  int32_t nbands;
+  const BandDesc* bands;    // [nbands] device
+  const int32_t* gen_list;  // [ngen] band ids of the general bands (pass 1 launch order)
+  int32_t ngen, ngen_launch;
+  const cplx<T>* X;      // [C][Lf] spectra of the records
+  const cplx<T>* Hc;     // compact bank of the pruned Gabor bands
+  const cplx<T>* Hfull;  // [ngen][Lf] full spectra of the general Gabor bands
+  cplx<T>* imd;          // [C][ngen][N2][N1] intermediate of the general bands
+  T inv_len;
+  // pass 2 outputs
+  cplx<T>* coef;
+  T* bits;
+  T* time_part;       // [C][nchunk][n]
+  double* part_band;  // [C][nbands][nblk]
+  double* part_stat;  // [C][nchunk][nblk][3]
+  int64_t nblk;       // N1 / G
+  int32_t bands_per_chunk;
+  T power_scale, eps;
+};
+
+template <typename T>
+int launch_pass1(const RowArgs<T>& a, bool stx, int64_t n_channels, hipStream_t st);
+template <typename T>
+int launch_pass2(const RowArgs<T>& a, bool stx, int nchunk, int64_t n_channels, hipStream_t st);
+int pass2_rows_per_group();
+template <typename T>
+int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st);
+int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st);
+template <typename T>
+int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
+                       hipStream_t st);
+
+}  // namespace native
+}  // namespace qi
