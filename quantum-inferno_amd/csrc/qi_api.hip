@@ -217,6 +217,8 @@ struct qi_plan {
     }
   } nat[3];
   int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
+  int native_debug = 0;
+  int native_rows = 16;        // consecutive time residues (rows) per pass-2 workgroup: 8 or 16
 };
 
 namespace {
@@ -458,7 +460,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const auto& t = p->nat[kind];
   const int64_t n = p->n, Lf = t.Lf, B = t.nbands;
   const T* sig = static_cast<const T*>(sig_v);
-  const int G = native::pass2_rows_per_group();
+  const int G = p->native_rows;
   const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
   int nchunk = (int)ceil_div(512, nblk * C);
   if (nchunk < 1) nchunk = 1;
@@ -504,8 +506,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.n = n;
     a.N1 = N1;
     a.N2 = native::kN2;
-    a.off = kind == 0 ? (n - 1) / 2 : (kind == 1 ? n / 2 : 0);
-    a.wrap = kind == 0 ? 0 : 1;
     a.nbands = (int32_t)B;
     a.bands = t.d_bands;
     a.gen_list = t.d_gen_list;
@@ -516,6 +516,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
     a.imd = imd;
     a.inv_len = (T)(1.0 / (double)Lf);
+    a.two_over_len = (float)(2.0 / (double)Lf);
+    a.debug = p->native_debug;
     a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
     a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
     a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
@@ -527,11 +529,11 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
     if (t.ngen > 0) {
       p->prof.begin(st);
-      QI_TRY(native::launch_pass1<T>(a, kind == 2, ct, st));
+      QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
       p->prof.end(QI_STAGE_PASS1, st);
     }
     p->prof.begin(st);
-    QI_TRY(native::launch_pass2<T>(a, kind == 2, nchunk, ct, st));
+    QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk, ct, st));
     p->prof.end(QI_STAGE_PASS2, st);
     p->prof.begin(st);
     if (time_via_part)
@@ -629,6 +631,13 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_KMAX")) {
     const long v = atol(e);
     if (v >= 0) p->native_kmax = v;
+  }
+  if (p->native_kmax > (int64_t)native::kMaxPrunedTerms * native::kN2)
+    p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
+  if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ROWS")) {
+    const long v = atol(e);
+    if (v == 8 || v == 16) p->native_rows = (int)v;
   }
   p->ws_bytes = desc->workspace_bytes > 0 ? (size_t)desc->workspace_bytes : ((size_t)2 << 30);
   if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {

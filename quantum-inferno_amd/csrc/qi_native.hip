@@ -81,16 +81,13 @@ __device__ __forceinline__ void fft_reg(cplx<T> (&v)[R]) {
   if constexpr (S > 1) fft_reg<T, R, DIR, S / 2>(v);
 }
 
-// exp(DIR * 2 pi i m / len) for an exact integer phase, single precision seeds
-__device__ __forceinline__ void unit_root(int64_t m, int64_t len, int dir, double* c, double* s) {
+// exp(+2 pi i m / Lf) for an exact integer phase m in [0, Lf), Lf = 2^p <= 2^24: the float argument
+// 2 m / Lf is exact, so the seeds are accurate to single precision whatever the size of m
+__device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double* c, double* s) {
   float sf, cf;
-  sincospif((float)(2.0 * (double)m / (double)len), &sf, &cf);
+  sincospif((float)m * two_over_len, &sf, &cf);
   *c = cf;
-  *s = dir > 0 ? sf : -sf;
-}
-__device__ __forceinline__ int64_t pmod(int64_t a, int64_t m) {
-  int64_t r = a % m;
-  return r < 0 ? r + m : r;
+  *s = sf;
 }
 
 template <typename T, int R2_, int G_, bool DFAST_>
@@ -107,34 +104,59 @@ struct Cfg {
 // ---- loaders: fill A[g][k] (row stride SR) for the G rows of this workgroup ---------------------------------------
 // pruned: A[g][k mod 1024] = sum_k Y[k] W_Lf^(k (t1_0 + g))
 template <typename T, class C, bool STX>
-__device__ __forceinline__ void load_pruned(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd, int64_t ch, int64_t t1_0) {
+__device__ __forceinline__ void load_pruned(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd,
+                                            const cplx<T>* __restrict__ X, uint32_t t1_0) {
+  constexpr int MAXM = kMaxPrunedTerms;  // support bins that can fall on one slot (k_len <= MAXM * 1024)
   const int tid = threadIdx.x;
-  const int64_t k_end = (int64_t)bd.k_lo + bd.k_len;
+  const uint32_t mask = (uint32_t)a.Lf - 1u;  // Lf is a power of two: x mod Lf == x & mask, also for negative x
+  const int32_t k_end = bd.k_lo + bd.k_len;
+  const cplx<T>* __restrict__ Hc = STX ? nullptr : a.Hc + bd.src_off;
+#pragma unroll 1
   for (int slot = tid; slot < C::NR; slot += C::TH) {
+    const int32_t k0 = bd.k_lo + ((slot - bd.k_lo) & (C::NR - 1));
+    // issue every global load of this slot first so that their latencies overlap
+    cplx<T> xs[MAXM], hs[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int32_t k = k0 + m * C::NR;
+      xs[m] = mk<T>(T(0), T(0));
+      hs[m] = mk<T>(T(1), T(0));
+      if (k < k_end) {
+        if constexpr (STX) {
+          xs[m] = X[(uint32_t)(k + (int32_t)bd.shift) & mask];
+        } else {
+          xs[m] = X[k];
+          hs[m] = Hc[k - bd.k_lo];
+        }
+      }
+    }
     cplx<T> acc[C::G];
 #pragma unroll
     for (int g = 0; g < C::G; ++g) acc[g] = mk<T>(T(0), T(0));
-    for (int64_t k = bd.k_lo + pmod(slot - bd.k_lo, C::NR); k < k_end; k += C::NR) {
-      cplx<T> y;
-      if constexpr (STX) {
-        const cplx<T> x = a.X[ch * a.Lf + pmod(k + bd.shift, a.Lf)];
-        const T e = (T)bd.coef * (T)k;
-        const T w = exp2_t(-e * e) * a.inv_len;
-        y = mk<T>(x.x * w, x.y * w);
-      } else {
-        y = cmul(a.X[ch * a.Lf + k], a.Hc[bd.src_off + (k - bd.k_lo)]);
-      }
-      double wr, wi, sr, si;
-      unit_root(pmod(k * t1_0, a.Lf), a.Lf, 1, &wr, &wi);
-      unit_root(pmod(k, a.Lf), a.Lf, 1, &sr, &si);
 #pragma unroll
-      for (int g = 0; g < C::G; ++g) {
-        const T cr = (T)wr, ci = (T)wi;
-        acc[g].x += y.x * cr - y.y * ci;
-        acc[g].y += y.x * ci + y.y * cr;
-        const double nr = wr * sr - wi * si;
-        wi = wr * si + wi * sr;
-        wr = nr;
+    for (int m = 0; m < MAXM; ++m) {
+      const int32_t k = k0 + m * C::NR;
+      if (k < k_end) {
+        cplx<T> y;
+        if constexpr (STX) {
+          const T e = (T)bd.coef * (T)k;
+          const T w = exp2_t(-e * e) * a.inv_len;
+          y = mk<T>(xs[m].x * w, xs[m].y * w);
+        } else {
+          y = cmul(xs[m], hs[m]);
+        }
+        double wr, wi, sr, si;
+        unit_root(((uint32_t)k * t1_0) & mask, a.two_over_len, &wr, &wi);
+        unit_root((uint32_t)k & mask, a.two_over_len, &sr, &si);
+#pragma unroll
+        for (int g = 0; g < C::G; ++g) {
+          const T cr = (T)wr, ci = (T)wi;
+          acc[g].x += y.x * cr - y.y * ci;
+          acc[g].y += y.x * ci + y.y * cr;
+          const double nr = wr * sr - wi * si;
+          wi = wr * si + wi * sr;
+          wr = nr;
+        }
       }
     }
 #pragma unroll
@@ -144,41 +166,83 @@ __device__ __forceinline__ void load_pruned(cplx<T>* A, const RowArgs<T>& a, con
 
 // general pass 2: A[g][k2] = imd[k2][t1_0 + g]  (G consecutive elements per k2, transposed through LDS)
 template <typename T, class C>
-__device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* imd, int64_t n1, int64_t t1_0) {
+__device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* __restrict__ imd, uint32_t n1, uint32_t t1_0) {
   const int tid = threadIdx.x;
   const int g = tid % C::G;
-  for (int k2 = tid / C::G; k2 < C::NR; k2 += C::TH / C::G) A[g * C::SR + k2] = imd[(int64_t)k2 * n1 + t1_0 + g];
+  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
+  static_assert(ITERS % BATCH == 0, "batch");
+  const cplx<T>* __restrict__ src = imd + t1_0 + g;
+#pragma unroll 1
+  for (int it = 0; it < ITERS; it += BATCH) {
+    cplx<T> v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) v[u] = src[(uint32_t)(tid / C::G + (it + u) * STEP) * n1];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) A[g * C::SR + tid / C::G + (it + u) * STEP] = v[u];
+  }
 }
 
 // general pass 1: A[r][k1] = Y[k2_0 + r + N2 k1]
 template <typename T, class C, bool STX>
-__device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd, int64_t ch, int64_t k2_0) {
+__device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd,
+                                          const cplx<T>* __restrict__ X, uint32_t k2_0) {
   const int tid = threadIdx.x;
   const int r = tid % C::G;
-  const cplx<T>* H = STX ? nullptr : a.Hfull + (int64_t)bd.gen_slot * a.Lf;
-  for (int k1 = tid / C::G; k1 < C::NR; k1 += C::TH / C::G) {
-    const int64_t k = k2_0 + r + (int64_t)a.N2 * k1;
-    cplx<T> y;
-    if constexpr (STX) {
-      const int64_t ks = (k <= (a.Lf - 1) / 2) ? k : k - a.Lf;
-      int64_t src = k + bd.shift;
-      if (src >= a.Lf) src -= a.Lf;
-      const cplx<T> x = a.X[ch * a.Lf + src];
-      const T e = (T)bd.coef * (T)ks;
-      const T w = exp2_t(-e * e) * a.inv_len;
-      y = mk<T>(x.x * w, x.y * w);
-    } else {
-      y = cmul(a.X[ch * a.Lf + k], H[k]);
+  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
+  static_assert(ITERS % BATCH == 0, "batch");
+  const uint32_t mask = (uint32_t)a.Lf - 1u;
+  const cplx<T>* __restrict__ H = STX ? nullptr : a.Hfull + (int64_t)bd.gen_slot * a.Lf;
+#pragma unroll 1
+  for (int it = 0; it < ITERS; it += BATCH) {
+    cplx<T> xs[BATCH], hs[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const uint32_t k = k2_0 + r + (uint32_t)kN2 * (uint32_t)(tid / C::G + (it + u) * STEP);
+      if constexpr (STX) {
+        xs[u] = X[(k + (uint32_t)bd.shift) & mask];
+      } else {
+        xs[u] = X[k];
+        hs[u] = H[k];
+      }
     }
-    A[r * C::SR + k1] = y;
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int k1 = tid / C::G + (it + u) * STEP;
+      cplx<T> y;
+      if constexpr (STX) {
+        const uint32_t k = k2_0 + r + (uint32_t)kN2 * (uint32_t)k1;
+        const int32_t ks = (k <= (mask >> 1)) ? (int32_t)k : (int32_t)k - (int32_t)(mask + 1u);
+        const T e = (T)bd.coef * (T)ks;
+        const T w = exp2_t(-e * e) * a.inv_len;
+        y = mk<T>(xs[u].x * w, xs[u].y * w);
+      } else {
+        y = cmul(xs[u], hs[u]);
+      }
+      A[r * C::SR + k1] = y;
+    }
   }
 }
+
+#ifdef QI_NATIVE_DEBUG
+#define QI_DBG(bit) (a.debug & (bit))
+#else
+#define QI_DBG(bit) false
+#endif
+
+__device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
+__device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 
 // ---- the row kernel ----------------------------------------------------------------------------------------------
 // PASS = 1: rows are k2 (G consecutive), transform over k1, write imd[k2][t1] * W_Lf^(k2 t1).
 // PASS = 2: rows are t1 (G consecutive), transform over k2, epilogue into the panel.
-template <typename T, class C, int PASS, bool STX>
+// KIND: 0 zero-padded linear correlation (Lf = 2n, keep [n/2 - 1, n/2 - 1 + n)), 1 circular correlation rolled by
+// n/2 (Lf = n), 2 Stockwell (Lf = n).  With t = t1 + N1 (d + 32 c) the crop / roll is a compile-time map of c:
+//   KIND 2: panel position i = c;  KIND 1: i = (c + 16) mod 32;  KIND 0: i = c - 8 for c in [8, 23], and the one
+//   sample t = n/2 - 1 (c = 7, d = 31, t1 = N1 - 1) takes the slot of the one sample past the end (c = 23).
+template <typename T, class C, int PASS, int KIND>
 __global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
+  constexpr bool STX = KIND == 2;
+  constexpr int NOUT = (PASS == 2 && KIND == 0) ? 16 : C::R2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
   cplx<T>* tw = buf + C::BUF;  // tw[d * R2 + a] = W_NR^(a d)
@@ -200,37 +264,42 @@ __global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
   const int g2 = C::DFAST ? tid / 32 : tid % C::G;
   const int d2 = C::DFAST ? tid % 32 : tid / C::G;
 
-  T col[C::R2];
+  T col[NOUT];
 #pragma unroll
-  for (int c = 0; c < C::R2; ++c) col[c] = T(0);
+  for (int c = 0; c < NOUT; ++c) col[c] = T(0);
   T mx = T(0);
   double plogp = 0.0;
-  int64_t jb0, jb1;
-  if constexpr (PASS == 1) {
-    jb0 = blockIdx.y;
-    jb1 = jb0 + 1;
-  } else {
-    jb0 = (int64_t)blockIdx.y * a.bands_per_chunk;
-    jb1 = jb0 + a.bands_per_chunk < a.nbands ? jb0 + a.bands_per_chunk : a.nbands;
-  }
+  // panel offset of this thread's first output and the stride between its outputs
+  const uint32_t tbase = (uint32_t)row0 + g2 + (uint32_t)a.N1 * d2 + (KIND == 0 ? 1u : 0u);
+  const uint32_t tstep = 32u * (uint32_t)a.N1;
+  const bool edge = KIND == 0 && d2 == 31 && (int64_t)row0 + g2 == a.N1 - 1;
+  // pass 1: one general band per workgroup; pass 2: bands blockIdx.y, blockIdx.y + nchunk, ... so that every
+  // chunk gets the same mix of narrow and wide bands
+  const int64_t jstep = PASS == 1 ? a.ngen_launch : gridDim.y;
+  const int64_t jend = PASS == 1 ? a.ngen_launch : a.nbands;
   int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
+  int par = 0;
 
-  for (int64_t jj = jb0; jj < jb1; ++jj) {
+  for (int64_t jj = blockIdx.y; jj < jend; jj += jstep) {
     const BandDesc bd = PASS == 1 ? a.bands[a.gen_list[jj]] : a.bands[jj];
     const int64_t j = PASS == 1 ? a.gen_list[jj] : jj;
     // ---- load
-    if constexpr (PASS == 1) {
-      load_full<T, C, STX>(buf, a, bd, ch, row0);
-    } else {
-      if (bd.mode == 0)
-        load_pruned<T, C, STX>(buf, a, bd, ch, row0);
-      else
-        load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, a.N1, row0);
+    const cplx<T>* Xc = a.X + ch * a.Lf;
+    if (!QI_DBG(2)) {
+      if constexpr (PASS == 1) {
+        load_full<T, C, STX>(buf, a, bd, Xc, (uint32_t)row0);
+      } else {
+        if (bd.mode == 0)
+          load_pruned<T, C, STX>(buf, a, bd, Xc, (uint32_t)row0);
+        else
+          load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, (uint32_t)a.N1, (uint32_t)row0);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (PASS == 2 && pending >= 0 && tid == 0) {
       double s = 0.0;
-      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[pending & 1][w];
+      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
       a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
     }
     // ---- step 1: R2 transforms of 32 points per row (over b), twiddle W_NR^(a d)
@@ -240,10 +309,13 @@ __global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
       const int aa = a1 + 32 * q;
 #pragma unroll
       for (int b = 0; b < 32; ++b) v[q][b] = buf[g1 * C::SR + aa + C::R2 * b];
-      fft_reg<T, 32, 1>(v[q]);
+      if (!QI_DBG(4)) {
+        fft_reg<T, 32, 1>(v[q]);
 #pragma unroll
-      for (int d = 1; d < 32; ++d) v[q][brev(d, 5)] = cmul(v[q][brev(d, 5)], tw[d * C::R2 + aa]);
+        for (int d = 1; d < 32; ++d) v[q][brev(d, 5)] = cmul(v[q][brev(d, 5)], tw[d * C::R2 + aa]);
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < C::NF1; ++q) {
@@ -252,61 +324,72 @@ __global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
       for (int d = 0; d < 32; ++d)
         buf[aa * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[q][brev(d, 5)];
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // ---- step 2: 32 transforms of R2 points per row (over a)
     cplx<T> u[C::R2];
 #pragma unroll
     for (int aa = 0; aa < C::R2; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    fft_reg<T, C::R2, 1>(u);
+    if (!QI_DBG(4)) fft_reg<T, C::R2, 1>(u);
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int LB = ilog2(C::R2);
 
     if constexpr (PASS == 1) {
       // imd[k2][t1] = u * W_Lf^(k2 t1), t1 = d2 + 32 c
-      const int64_t k2 = row0 + g2;
-      cplx<T>* dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
+      const uint32_t k2 = (uint32_t)row0 + g2;
+      cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
+      const uint32_t mask = (uint32_t)a.Lf - 1u;
       double wr, wi, sr, si;
-      unit_root(pmod(k2 * d2, a.Lf), a.Lf, 1, &wr, &wi);
-      unit_root(pmod(k2 * 32, a.Lf), a.Lf, 1, &sr, &si);
+      unit_root((k2 * (uint32_t)d2) & mask, a.two_over_len, &wr, &wi);
+      unit_root((k2 * 32u) & mask, a.two_over_len, &sr, &si);
 #pragma unroll
       for (int c = 0; c < C::R2; ++c) {
         const cplx<T> z = u[brev(c, LB)];
         const T cr = (T)wr, ci = (T)wi;
-        dst[d2 + 32 * c] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
+        if (!QI_DBG(1)) dst[d2 + 32 * c] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
+        else if (z.x == T(123.456)) dst[0] = z;
         const double nr = wr * sr - wi * si;
         wi = wr * si + wi * sr;
         wr = nr;
       }
     } else {
-      const int64_t t1 = row0 + g2;
       const int64_t orow = ((int64_t)ch * a.nbands + j) * a.n;
-      T rowacc = T(0);
+      char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+      char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+      // the output offsets do not depend on the band; hide that from the optimiser, which would otherwise hoist
+      // every address out of the band loop and spill them
+      uint32_t tb = tbase;
+      asm volatile("" : "+v"(tb));
+      T rowacc = T(0), pl = T(0);
 #pragma unroll
-      for (int c = 0; c < C::R2; ++c) {
-        const cplx<T> z = u[brev(c, LB)];
-        const int64_t t = t1 + a.N1 * (int64_t)(d2 + 32 * c);
-        int64_t tt = t - a.off;
-        bool ok = true;
-        if (a.wrap) {
-          if (tt < 0) tt += a.n;
-        } else {
-          ok = tt >= 0 && tt < a.n;
+      for (int i = 0; i < NOUT; ++i) {
+        constexpr int cmap_lin = 8, cmap_rot = 16;
+        const int c = KIND == 0 ? i + cmap_lin : (KIND == 1 ? ((i + cmap_rot) & 31) : i);
+        cplx<T> z = u[brev(c, LB)];
+        uint32_t tt = tb + (uint32_t)i * tstep;
+        if (KIND == 0 && i == NOUT - 1 && edge) {
+          z = u[brev(7, LB)];
+          tt = 0;
         }
-        if (ok) {
-          if (a.coef) a.coef[orow + tt] = z;
-          const T m2 = z.x * z.x + z.y * z.y;
-          if (a.bits) a.bits[orow + tt] = log2_t(sqrt_t(m2) + a.eps);
-          const T p = a.power_scale * m2;
-          col[c] += p;
+        if (coef_row && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+        const T m2 = z.x * z.x + z.y * z.y;
+        if (bits_row) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
+        const T p = a.power_scale * m2;
+        col[i] += p;
+        if (!QI_DBG(8)) {
           rowacc += p;
           mx = p > mx ? p : mx;
-          if (p > T(0)) plogp += (double)(p * log2_t(p));
+          pl += plog2p(p);
         }
       }
+      plogp += (double)pl;
       if (a.part_band) {
         const double r = wave_sum((double)rowacc);
-        if (lane == 0) s_red[j & 1][wv] = r;
+        if (lane == 0) s_red[par][wv] = r;
         pending = j;
+        par ^= 1;
       }
     }
   }
@@ -315,25 +398,18 @@ __global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
     __syncthreads();
     if (pending >= 0 && tid == 0) {
       double s = 0.0;
-      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[pending & 1][w];
+      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
       a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
     }
     T tot = T(0);
-    const int64_t t1 = row0 + g2;
+    char* __restrict__ time_row =
+        reinterpret_cast<char*>(a.time_part ? a.time_part + ((int64_t)ch * gridDim.y + blockIdx.y) * a.n : nullptr);
 #pragma unroll
-    for (int c = 0; c < C::R2; ++c) {
-      tot += col[c];
-      if (a.time_part) {
-        const int64_t t = t1 + a.N1 * (int64_t)(d2 + 32 * c);
-        int64_t tt = t - a.off;
-        bool ok = true;
-        if (a.wrap) {
-          if (tt < 0) tt += a.n;
-        } else {
-          ok = tt >= 0 && tt < a.n;
-        }
-        if (ok) a.time_part[((int64_t)ch * gridDim.y + blockIdx.y) * a.n + tt] = col[c];
-      }
+    for (int i = 0; i < NOUT; ++i) {
+      tot += col[i];
+      uint32_t tt = tbase + (uint32_t)i * tstep;
+      if (KIND == 0 && i == NOUT - 1 && edge) tt = 0;
+      if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = col[i];
     }
     if (a.part_stat) {
       const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
@@ -440,10 +516,10 @@ __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict
     }                                                                                    \
   } while (0)
 
-template <typename T, class C, int PASS, bool STX>
+template <typename T, class C, int PASS, int KIND>
 static int launch_rows(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
   static bool configured = false;
-  auto kern = k_rows<T, C, PASS, STX>;
+  auto kern = k_rows<T, C, PASS, KIND>;
   if (!configured) {
     QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)C::LDS_BYTES));
@@ -454,31 +530,50 @@ static int launch_rows(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
   return QI_OK;
 }
 
+template <typename T, class C, int PASS>
+static int launch_rows_kind(const RowArgs<T>& a, int kind, dim3 grid, hipStream_t st) {
+  if (PASS == 1)  // pass 1 only distinguishes the Stockwell window from a stored bank row
+    return kind == 2 ? launch_rows<T, C, PASS, 2>(a, grid, st) : launch_rows<T, C, PASS, 0>(a, grid, st);
+  switch (kind) {
+    case 0: return launch_rows<T, C, PASS, 0>(a, grid, st);
+    case 1: return launch_rows<T, C, PASS, 1>(a, grid, st);
+    default: return launch_rows<T, C, PASS, 2>(a, grid, st);
+  }
+}
+
 template <>
-int launch_pass1<float>(const RowArgs<float>& a, bool stx, int64_t n_channels, hipStream_t st) {
+int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
   if (a.ngen_launch <= 0) return QI_OK;
   if (a.N1 == 1024) {
     using C = Cfg<float, 32, 16, true>;
     dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
-    return stx ? launch_rows<float, C, 1, true>(a, grid, st) : launch_rows<float, C, 1, false>(a, grid, st);
+    return launch_rows_kind<float, C, 1>(a, kind, grid, st);
   }
   if (a.N1 == 2048) {
     using C = Cfg<float, 64, 8, true>;
     dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
-    return stx ? launch_rows<float, C, 1, true>(a, grid, st) : launch_rows<float, C, 1, false>(a, grid, st);
+    return launch_rows_kind<float, C, 1>(a, kind, grid, st);
   }
   set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
   return QI_ERR_UNSUPPORTED;
 }
 
 template <>
-int launch_pass2<float>(const RowArgs<float>& a, bool stx, int nchunk, int64_t n_channels, hipStream_t st) {
-  using C = Cfg<float, 32, 16, false>;
-  dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
-  return stx ? launch_rows<float, C, 2, true>(a, grid, st) : launch_rows<float, C, 2, false>(a, grid, st);
+int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
+                        hipStream_t st) {
+  if (rows_per_group == 16) {
+    using C = Cfg<float, 32, 16, false>;
+    dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
+    return launch_rows_kind<float, C, 2>(a, kind, grid, st);
+  }
+  if (rows_per_group == 8) {  // half the LDS image: two workgroups per CU hide each other's barriers
+    using C = Cfg<float, 32, 8, false>;
+    dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
+    return launch_rows_kind<float, C, 2>(a, kind, grid, st);
+  }
+  set_error("pass 2 supports 8 or 16 rows per workgroup, got %d", rows_per_group);
+  return QI_ERR_UNSUPPORTED;
 }
-
-int pass2_rows_per_group() { return 16; }
 
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st) {

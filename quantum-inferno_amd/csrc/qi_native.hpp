@@ -6,6 +6,7 @@ namespace qi {
 namespace native {
 
 constexpr int kN2 = 1024;  // points of the in-LDS row transform of pass 2
+constexpr int kMaxPrunedTerms = 8;  // widest pruned support = kMaxPrunedTerms * kN2 spectrum bins
 
 struct BandDesc {
   int32_t mode;      // 0: pruned (spectrum support short enough for the one-pass loader), 1: general
@@ -19,8 +20,7 @@ struct BandDesc {
 
 template <typename T>
 struct RowArgs {
-  int64_t Lf, n, N1, N2, off;
-  int32_t wrap;  // 1: out index (t - off) mod n (circular / Stockwell), 0: crop [off, off + n)
+  int64_t Lf, n, N1, N2;
   int32_t nbands;
   const BandDesc* bands;    // [nbands] device
   const int32_t* gen_list;  // [ngen] band ids of the general bands (pass 1 launch order)
@@ -30,6 +30,7 @@ struct RowArgs {
   const cplx<T>* Hfull;  // [ngen][Lf] full spectra of the general Gabor bands
   cplx<T>* imd;          // [C][ngen][N2][N1] intermediate of the general bands
   T inv_len;
+  float two_over_len;  // 2 / Lf (exact)
   // pass 2 outputs
   cplx<T>* coef;
   T* bits;
@@ -39,13 +40,13 @@ struct RowArgs {
   int64_t nblk;       // N1 / G
   int32_t bands_per_chunk;
   T power_scale, eps;
+  int32_t debug;  // QI_NATIVE_DEBUG bit mask (timing experiments only: 1 no stores, 2 no loads, 4 no FFT, 8 no reductions)
 };
 
 template <typename T>
-int launch_pass1(const RowArgs<T>& a, bool stx, int64_t n_channels, hipStream_t st);
+int launch_pass1(const RowArgs<T>& a, int kind, int64_t n_channels, hipStream_t st);
 template <typename T>
-int launch_pass2(const RowArgs<T>& a, bool stx, int nchunk, int64_t n_channels, hipStream_t st);
-int pass2_rows_per_group();
+int launch_pass2(const RowArgs<T>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st);
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st);
