@@ -1,0 +1,83 @@
+"""world_size-2 `gloo` test of the multi-GPU leg on CPU: contiguous channel sharding and the single
+gather of the reduced TFR product to rank 0 (quantum-inferno_amd/dist.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_ch, n_b, n, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quantum_inferno_amd import dist as qdist
+    from quantum_inferno_amd.engine import TfrResult
+
+    first, count = qdist.shard(total_ch, rank, world)
+    results = []
+    for panel in range(2):  # CWT and STX reduced products of this rank's channels
+        ch = torch.arange(first, first + count, dtype=torch.float64).reshape(-1, 1)
+        band = ch * 1000 + panel * 100 + torch.arange(n_b, dtype=torch.float64)[None, :]
+        time = (ch * 10 + panel + torch.arange(n, dtype=torch.float64)[None, :] / n).to(torch.float32)
+        stats = torch.cat([ch + panel, ch * 2, ch * 3, torch.zeros_like(ch)], dim=1)
+        results.append(TfrResult(frequency_hz=np.arange(n_b), power_band=band, power_time=time, stats=stats))
+    flat = qdist.pack_reduced(results)
+    got = qdist.gather_reduced(flat, dst=0)
+    if rank == 0:
+        torch.save(got, os.path.join(out_dir, "gathered.pt"))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_partitions_every_channel_once():
+    from quantum_inferno_amd import dist as qdist
+
+    for total in (1, 7, 8, 64, 512, 1024):
+        for world in (1, 2, 3, 8):
+            spans = [qdist.shard(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_gather_of_reduced_product_world2(tmp_path):
+    total_ch, n_b, n, world = 6, 5, 16, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total_ch, n_b, n, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "gathered.pt"))
+    sys.path.insert(0, ROOT)
+    from quantum_inferno_amd import dist as qdist
+
+    assert got.shape == (world, 2 * 3 * (n_b + n + 4))
+    for rank in range(world):
+        first, count = qdist.shard(total_ch, rank, world)
+        parts = qdist.unpack_reduced(got[rank], count, [(n_b, n), (n_b, n)])
+        for panel, (band, time, stats) in enumerate(parts):
+            ch = torch.arange(first, first + count, dtype=torch.float64).reshape(-1, 1)
+            assert torch.equal(band, ch * 1000 + panel * 100 + torch.arange(n_b, dtype=torch.float64)[None, :])
+            assert torch.allclose(time, ch * 10 + panel + torch.arange(n, dtype=torch.float64)[None, :] / n, atol=1e-6)
+            assert torch.equal(stats[:, 0:1], ch + panel) and torch.equal(stats[:, 2:3], ch * 3)
+
+
+def test_single_process_gather_is_identity():
+    from quantum_inferno_amd import dist as qdist
+
+    flat = torch.arange(10, dtype=torch.float64)
+    assert torch.equal(qdist.gather_reduced(flat)[0], flat)
