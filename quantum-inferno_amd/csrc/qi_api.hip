@@ -518,6 +518,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.inv_len = (T)(1.0 / (double)Lf);
     a.two_over_len = (float)(2.0 / (double)Lf);
     a.debug = p->native_debug;
+    a.neg_last_row = kind == 0 ? 1 : 0;
     a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
     a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
     a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);

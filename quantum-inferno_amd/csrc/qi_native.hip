@@ -81,6 +81,12 @@ __device__ __forceinline__ void fft_reg(cplx<T> (&v)[R]) {
   if constexpr (S > 1) fft_reg<T, R, DIR, S / 2>(v);
 }
 
+// v[brev(c)] *= W_64^c for c = 0..31 (the radix-2 combination twiddles of a 2048-point row)
+template <typename T, int... Cs>
+__device__ __forceinline__ void mul_w64_powers(cplx<T> (&v)[32], std::integer_sequence<int, Cs...>) {
+  ((v[brev(Cs, 5)] = mul_tw64<T, Cs, 1>(v[brev(Cs, 5)])), ...);
+}
+
 // exp(+2 pi i m / Lf) for an exact integer phase m in [0, Lf), Lf = 2^p <= 2^24: the float argument
 // 2 m / Lf is exact, so the seeds are accurate to single precision whatever the size of m
 __device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double* c, double* s) {
@@ -90,16 +96,25 @@ __device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double
   *s = sf;
 }
 
-template <typename T, int R2_, int G_, bool DFAST_>
+// Geometry of one workgroup: G rows of 1024 points, 32 threads per row.
+template <typename T, int G_, bool DFAST_>
 struct Cfg {
-  static constexpr int R1 = 32, R2 = R2_, NR = 32 * R2_, G = G_, TH = 32 * G_;
-  static constexpr bool DFAST = DFAST_;
-  static constexpr int SR = NR + 1;      // row stride of the natural-order image A[g][k]
-  static constexpr int SA = 32 * G_ + 1; // a-stride of the exchange image E[a][...]
-  static constexpr int BUF = (G_ * SR > R2_ * SA) ? G_ * SR : R2_ * SA;
-  static constexpr int NF1 = R2_ / 32;   // step-1 FFTs per thread
+  static constexpr int NR = 1024, G = G_, TH = 32 * G_;
+  static constexpr bool DFAST = DFAST_;   // step-2 lanes run over d (pass 1: rows are contiguous in t1) or over g
+  static constexpr int SR = NR + 1;       // row stride of the natural-order image A[g][k]
+  static constexpr int SA = 32 * G_ + 1;  // a-stride of the exchange image E[a][...]
+  static constexpr int BUF = (G_ * SR > 32 * SA) ? G_ * SR : 32 * SA;
   static constexpr size_t LDS_BYTES = ((size_t)BUF + NR) * sizeof(cplx<T>) + 256;
 };
+
+#ifdef QI_NATIVE_DEBUG
+#define QI_DBG(bit) (a.debug & (bit))
+#else
+#define QI_DBG(bit) false
+#endif
+
+__device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
+__device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 
 // ---- loaders: fill A[g][k] (row stride SR) for the G rows of this workgroup ---------------------------------------
 // pruned: A[g][k mod 1024] = sum_k Y[k] W_Lf^(k (t1_0 + g))
@@ -169,9 +184,9 @@ template <typename T, class C>
 __device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* __restrict__ imd, uint32_t n1, uint32_t t1_0) {
   const int tid = threadIdx.x;
   const int g = tid % C::G;
-  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
+  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 16;
   static_assert(ITERS % BATCH == 0, "batch");
-  const cplx<T>* __restrict__ src = imd + t1_0 + g;
+  const cplx<T>* __restrict__ src = imd + t1_0 + g;  // imd columns are r = t1 + imd_roll, see pass 1
 #pragma unroll 1
   for (int it = 0; it < ITERS; it += BATCH) {
     cplx<T> v[BATCH];
@@ -182,10 +197,10 @@ __device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* __restrict__
   }
 }
 
-// general pass 1: A[r][k1] = Y[k2_0 + r + N2 k1]
-template <typename T, class C, bool STX>
+// general pass 1: A[r][m] = Y[k2_0 + r + N2 (NPH m + ph)]   (phase ph of NPH interleaved sub-sequences of k1)
+template <typename T, class C, bool STX, int NPH>
 __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd,
-                                          const cplx<T>* __restrict__ X, uint32_t k2_0) {
+                                          const cplx<T>* __restrict__ X, uint32_t k2_0, int ph) {
   const int tid = threadIdx.x;
   const int r = tid % C::G;
   constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
@@ -197,7 +212,8 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
     cplx<T> xs[BATCH], hs[BATCH];
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
-      const uint32_t k = k2_0 + r + (uint32_t)kN2 * (uint32_t)(tid / C::G + (it + u) * STEP);
+      const uint32_t m = (uint32_t)(tid / C::G + (it + u) * STEP);
+      const uint32_t k = k2_0 + r + (uint32_t)kN2 * (NPH * m + ph);
       if constexpr (STX) {
         xs[u] = X[(k + (uint32_t)bd.shift) & mask];
       } else {
@@ -207,10 +223,10 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
     }
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
-      const int k1 = tid / C::G + (it + u) * STEP;
+      const uint32_t m = (uint32_t)(tid / C::G + (it + u) * STEP);
       cplx<T> y;
       if constexpr (STX) {
-        const uint32_t k = k2_0 + r + (uint32_t)kN2 * (uint32_t)k1;
+        const uint32_t k = k2_0 + r + (uint32_t)kN2 * (NPH * m + ph);
         const int32_t ks = (k <= (mask >> 1)) ? (int32_t)k : (int32_t)k - (int32_t)(mask + 1u);
         const T e = (T)bd.coef * (T)ks;
         const T w = exp2_t(-e * e) * a.inv_len;
@@ -218,219 +234,260 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
       } else {
         y = cmul(xs[u], hs[u]);
       }
-      A[r * C::SR + k1] = y;
+      A[r * C::SR + m] = y;
     }
   }
 }
 
-#ifdef QI_NATIVE_DEBUG
-#define QI_DBG(bit) (a.debug & (bit))
-#else
-#define QI_DBG(bit) false
-#endif
+// tw[d * 32 + a] = W_1024^(a d): the twiddle between the two radix-32 steps, lanes run over a
+template <typename T, class C>
+__device__ __forceinline__ void fill_step_twiddles(cplx<T>* tw) {
+  for (int i = threadIdx.x; i < C::NR; i += C::TH) {
+    const int d = i / 32, aa = i % 32;
+    float sf, cf;
+    sincospif((float)(2 * (aa * d)) / (float)C::NR, &sf, &cf);
+    tw[i] = mk<T>((T)cf, (T)sf);
+  }
+}
 
-__device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
-__device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
+// 1024-point inverse transform of the G rows held in buf (natural order, row stride SR), all threads of the
+// workgroup: two register radix-32 steps and one exchange through LDS.  The caller has synchronised after filling
+// buf; on return buf is free again and thread (g2, d2) holds out[d2 + 32 c] in u[brev(c, 5)].
+template <typename T, class C>
+__device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[32], bool skip) {
+  const int tid = threadIdx.x;
+  const int g1 = tid / 32, a1 = tid % 32;
+  const int g2 = C::DFAST ? tid / 32 : tid % C::G;
+  const int d2 = C::DFAST ? tid % 32 : tid / C::G;
+  // step 1: per row 32 transforms over b of x[a + 32 b], then the twiddle W_1024^(a d)
+  cplx<T> v[32];
+#pragma unroll
+  for (int b = 0; b < 32; ++b) v[b] = buf[g1 * C::SR + a1 + 32 * b];
+  if (!skip) {
+    fft_reg<T, 32, 1>(v);
+#pragma unroll
+    for (int d = 1; d < 32; ++d) v[brev(d, 5)] = cmul(v[brev(d, 5)], tw[d * 32 + a1]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 32; ++d) buf[a1 * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[brev(d, 5)];
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  // step 2: per row 32 transforms over a
+#pragma unroll
+  for (int aa = 0; aa < 32; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  if (!skip) fft_reg<T, 32, 1>(u);
+  __builtin_amdgcn_sched_barrier(0);
+}
 
-// ---- the row kernel ----------------------------------------------------------------------------------------------
-// PASS = 1: rows are k2 (G consecutive), transform over k1, write imd[k2][t1] * W_Lf^(k2 t1).
-// PASS = 2: rows are t1 (G consecutive), transform over k2, epilogue into the panel.
-// KIND: 0 zero-padded linear correlation (Lf = 2n, keep [n/2 - 1, n/2 - 1 + n)), 1 circular correlation rolled by
-// n/2 (Lf = n), 2 Stockwell (Lf = n).  With t = t1 + N1 (d + 32 c) the crop / roll is a compile-time map of c:
-//   KIND 2: panel position i = c;  KIND 1: i = (c + 16) mod 32;  KIND 0: i = c - 8 for c in [8, 23], and the one
-//   sample t = n/2 - 1 (c = 7, d = 31, t1 = N1 - 1) takes the slot of the one sample past the end (c = 23).
-template <typename T, class C, int PASS, int KIND>
-__global__ void __launch_bounds__(C::TH) k_rows(RowArgs<T> a) {
-  constexpr bool STX = KIND == 2;
-  constexpr int NOUT = (PASS == 2 && KIND == 0) ? 16 : C::R2;
+// ---- pass 1 (wide bands only) ---------------------------------------------------------------------------------------
+// Rows are G consecutive k2; the transform runs over k1 (N1 = 1024 NPH points) and the result, multiplied by the
+// pass twiddle W_Lf^(k2 t1), is written to imd[k2][t1] in rows of N1 contiguous values.  N1 = 2048 is evaluated as
+// two 1024-point transforms of the even and odd k1 (each reading every 128-byte line of the operands exactly once)
+// combined by one radix-2 step in registers.
+template <typename T, class C, bool STX, int NPH>
+__global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* tw = buf + C::BUF;  // tw[d * R2 + a] = W_NR^(a d)
+  cplx<T>* tw = buf + C::BUF;
+  const int tid = threadIdx.x;
+  const int64_t ch = blockIdx.z;
+  const uint32_t row0 = blockIdx.x * C::G;
+  const int g2 = tid / 32, d2 = tid % 32;  // DFAST mapping
+  fill_step_twiddles<T, C>(tw);
+  const int32_t j = a.gen_list[blockIdx.y];
+  const BandDesc bd = a.bands[j];
+  const cplx<T>* Xc = a.X + ch * a.Lf;
+  const uint32_t mask = (uint32_t)a.Lf - 1u;
+
+  cplx<T> u[NPH][32];
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph) {
+    if (!QI_DBG(2)) load_full<T, C, STX, NPH>(buf, a, bd, Xc, row0, ph);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    rows_fft1024<T, C>(buf, tw, u[ph], QI_DBG(4));
+  }
+  const uint32_t k2 = row0 + g2;
+  // The linear kind's pass 2 works on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken
+  // at -1): columns are stored at r = (t1 + 1) mod N1 so that pass 2 reads aligned runs of G columns.
+  cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
+  const uint32_t roll = a.neg_last_row ? 1u : 0u, cmask = (uint32_t)a.N1 - 1u;
+  // pass twiddle W_Lf^(k2 t1) along t1 = d2 + 32 c by a float64 recurrence from single-precision seeds
+  double wr, wi, sr, si;
+  unit_root((k2 * (uint32_t)d2) & mask, a.two_over_len, &wr, &wi);
+  unit_root((k2 * 32u) & mask, a.two_over_len, &sr, &si);
+  if constexpr (NPH == 1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const cplx<T> z = u[0][brev(c, 5)];
+      if (c == 31 && a.neg_last_row && d2 == 31)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
+        unit_root((0u - k2) & mask, a.two_over_len, &wr, &wi);
+      const T cr = (T)wr, ci = (T)wi;
+      if (!QI_DBG(1)) dst[(d2 + 32u * c + roll) & cmask] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
+      const double nr = wr * sr - wi * si;
+      wi = wr * si + wi * sr;
+      wr = nr;
+    }
+  } else {
+    // X[t] = E[t] + W_2048^t O[t], X[t + 1024] = E[t] - W_2048^t O[t], t = d2 + 32 c; W_2048^t = W_2048^d2 W_64^c
+    float s2, c2;
+    sincospif((float)d2 * (1.0f / 1024.0f), &s2, &c2);
+    double hr, hi;  // W_Lf^(1024 k2): ratio between the pass twiddles of t + 1024 and t
+    unit_root((k2 * 1024u) & mask, a.two_over_len, &hr, &hi);
+    const T hrf = (T)hr, hif = (T)hi;
+    mul_w64_powers<T>(u[1], std::make_integer_sequence<int, 32>{});
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      const cplx<T> e = u[0][brev(c, 5)];
+      const cplx<T> o = cmul(u[1][brev(c, 5)], mk<T>((T)c2, (T)s2));
+      const cplx<T> lo = mk<T>(e.x + o.x, e.y + o.y), hi2 = mk<T>(e.x - o.x, e.y - o.y);
+      const T cr = (T)wr, ci = (T)wi;
+      T ur = cr * hrf - ci * hif, ui = cr * hif + ci * hrf;  // twiddle of t + 1024
+      if (c == 31 && a.neg_last_row && d2 == 31) {
+        double nr2, ni2;
+        unit_root((0u - k2) & mask, a.two_over_len, &nr2, &ni2);
+        ur = (T)nr2;
+        ui = (T)ni2;
+      }
+      if (!QI_DBG(1)) {
+        dst[(d2 + 32u * c + roll) & cmask] = mk<T>(lo.x * cr - lo.y * ci, lo.x * ci + lo.y * cr);
+        dst[(d2 + 32u * c + 1024u + roll) & cmask] = mk<T>(hi2.x * ur - hi2.y * ui, hi2.x * ui + hi2.y * ur);
+      }
+      const double nr = wr * sr - wi * si;
+      wi = wr * si + wi * sr;
+      wr = nr;
+    }
+  }
+}
+
+// ---- pass 2 (every band) ---------------------------------------------------------------------------------------------
+// Rows are G consecutive time residues t1; the transform runs over k2 and the epilogue crops / rolls into the
+// panel and takes the tfr_info reductions from registers.
+// KIND: 0 zero-padded linear correlation (Lf = 2n, keep [n/2 - 1, n/2 - 1 + n)), 1 circular correlation rolled by
+// n/2 (Lf = n), 2 Stockwell (Lf = n).  With t = t1 + N1 (d + 32 c) the crop / roll is a compile-time map of c:
+//   KIND 2: panel position i = c;  KIND 1: i = (c + 16) mod 32;  KIND 0: i = c - 8 for c in [8, 24) (16 of the 32
+//   outputs of a thread are kept, the others are never computed: the dead butterflies are eliminated).
+template <typename T, class C, int KIND>
+__global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
+  constexpr bool STX = KIND == 2;
+  constexpr int NOUT = KIND == 0 ? 16 : 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* tw = buf + C::BUF;
   __shared__ double s_red[2][C::TH / kWave];
   __shared__ double s_fin[3][C::TH / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t grp = blockIdx.x, ch = blockIdx.z;
-  const int64_t row0 = grp * C::G;
-
-  for (int i = tid; i < C::NR; i += C::TH) {
-    const int d = i / C::R2, aa = i % C::R2;
-    float sf, cf;
-    sincospif((float)(2 * ((aa * d) % C::NR)) / (float)C::NR, &sf, &cf);
-    tw[i] = mk<T>((T)cf, (T)sf);
-  }
-
-  // step-1 / step-2 thread coordinates
-  const int g1 = tid / 32, a1 = tid % 32;
-  const int g2 = C::DFAST ? tid / 32 : tid % C::G;
-  const int d2 = C::DFAST ? tid % 32 : tid / C::G;
+  const uint32_t row0 = (uint32_t)grp * C::G;
+  const int g2 = tid % C::G, d2 = tid / C::G;
+  fill_step_twiddles<T, C>(tw);
 
   T col[NOUT];
 #pragma unroll
   for (int c = 0; c < NOUT; ++c) col[c] = T(0);
   T mx = T(0);
   double plogp = 0.0;
+  // The linear kind works on the time residues t1 = r - 1, r = row0 + g (so r = 0 is t1 = -1, i.e. the samples
+  // N1 t2 - 1): the kept samples [n/2 - 1, 3n/2 - 1) are then exactly c in [8, 24) for every row and each run of
+  // G outputs starts on a 128-byte boundary of the panel.
+  const uint32_t t1_first = row0 - (KIND == 0 ? 1u : 0u);
   // panel offset of this thread's first output and the stride between its outputs
-  const uint32_t tbase = (uint32_t)row0 + g2 + (uint32_t)a.N1 * d2 + (KIND == 0 ? 1u : 0u);
+  const uint32_t tbase = row0 + g2 + (uint32_t)a.N1 * d2;
   const uint32_t tstep = 32u * (uint32_t)a.N1;
-  const bool edge = KIND == 0 && d2 == 31 && (int64_t)row0 + g2 == a.N1 - 1;
-  // pass 1: one general band per workgroup; pass 2: bands blockIdx.y, blockIdx.y + nchunk, ... so that every
-  // chunk gets the same mix of narrow and wide bands
-  const int64_t jstep = PASS == 1 ? a.ngen_launch : gridDim.y;
-  const int64_t jend = PASS == 1 ? a.ngen_launch : a.nbands;
+  const cplx<T>* Xc = a.X + ch * a.Lf;
   int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
   int par = 0;
 
-  for (int64_t jj = blockIdx.y; jj < jend; jj += jstep) {
-    const BandDesc bd = PASS == 1 ? a.bands[a.gen_list[jj]] : a.bands[jj];
-    const int64_t j = PASS == 1 ? a.gen_list[jj] : jj;
-    // ---- load
-    const cplx<T>* Xc = a.X + ch * a.Lf;
+  // bands blockIdx.y, blockIdx.y + nchunk, ...: every chunk gets the same mix of narrow and wide bands
+  for (int64_t j = blockIdx.y; j < a.nbands; j += gridDim.y) {
+    const BandDesc bd = a.bands[j];
     if (!QI_DBG(2)) {
-      if constexpr (PASS == 1) {
-        load_full<T, C, STX>(buf, a, bd, Xc, (uint32_t)row0);
-      } else {
-        if (bd.mode == 0)
-          load_pruned<T, C, STX>(buf, a, bd, Xc, (uint32_t)row0);
-        else
-          load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, (uint32_t)a.N1, (uint32_t)row0);
-      }
+      if (bd.mode == 0)
+        load_pruned<T, C, STX>(buf, a, bd, Xc, t1_first);
+      else
+        load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, (uint32_t)a.N1, row0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (PASS == 2 && pending >= 0 && tid == 0) {
-      double s = 0.0;
-      for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
-      a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
-    }
-    // ---- step 1: R2 transforms of 32 points per row (over b), twiddle W_NR^(a d)
-    cplx<T> v[C::NF1][32];
-#pragma unroll
-    for (int q = 0; q < C::NF1; ++q) {
-      const int aa = a1 + 32 * q;
-#pragma unroll
-      for (int b = 0; b < 32; ++b) v[q][b] = buf[g1 * C::SR + aa + C::R2 * b];
-      if (!QI_DBG(4)) {
-        fft_reg<T, 32, 1>(v[q]);
-#pragma unroll
-        for (int d = 1; d < 32; ++d) v[q][brev(d, 5)] = cmul(v[q][brev(d, 5)], tw[d * C::R2 + aa]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < C::NF1; ++q) {
-      const int aa = a1 + 32 * q;
-#pragma unroll
-      for (int d = 0; d < 32; ++d)
-        buf[aa * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[q][brev(d, 5)];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    // ---- step 2: 32 transforms of R2 points per row (over a)
-    cplx<T> u[C::R2];
-#pragma unroll
-    for (int aa = 0; aa < C::R2; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (!QI_DBG(4)) fft_reg<T, C::R2, 1>(u);
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int LB = ilog2(C::R2);
-
-    if constexpr (PASS == 1) {
-      // imd[k2][t1] = u * W_Lf^(k2 t1), t1 = d2 + 32 c
-      const uint32_t k2 = (uint32_t)row0 + g2;
-      cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
-      const uint32_t mask = (uint32_t)a.Lf - 1u;
-      double wr, wi, sr, si;
-      unit_root((k2 * (uint32_t)d2) & mask, a.two_over_len, &wr, &wi);
-      unit_root((k2 * 32u) & mask, a.two_over_len, &sr, &si);
-#pragma unroll
-      for (int c = 0; c < C::R2; ++c) {
-        const cplx<T> z = u[brev(c, LB)];
-        const T cr = (T)wr, ci = (T)wi;
-        if (!QI_DBG(1)) dst[d2 + 32 * c] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
-        else if (z.x == T(123.456)) dst[0] = z;
-        const double nr = wr * sr - wi * si;
-        wi = wr * si + wi * sr;
-        wr = nr;
-      }
-    } else {
-      const int64_t orow = ((int64_t)ch * a.nbands + j) * a.n;
-      char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
-      char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
-      // the output offsets do not depend on the band; hide that from the optimiser, which would otherwise hoist
-      // every address out of the band loop and spill them
-      uint32_t tb = tbase;
-      asm volatile("" : "+v"(tb));
-      T rowacc = T(0), pl = T(0);
-#pragma unroll
-      for (int i = 0; i < NOUT; ++i) {
-        constexpr int cmap_lin = 8, cmap_rot = 16;
-        const int c = KIND == 0 ? i + cmap_lin : (KIND == 1 ? ((i + cmap_rot) & 31) : i);
-        cplx<T> z = u[brev(c, LB)];
-        uint32_t tt = tb + (uint32_t)i * tstep;
-        if (KIND == 0 && i == NOUT - 1 && edge) {
-          z = u[brev(7, LB)];
-          tt = 0;
-        }
-        if (coef_row && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
-        const T m2 = z.x * z.x + z.y * z.y;
-        if (bits_row) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
-        const T p = a.power_scale * m2;
-        col[i] += p;
-        if (!QI_DBG(8)) {
-          rowacc += p;
-          mx = p > mx ? p : mx;
-          pl += plog2p(p);
-        }
-      }
-      plogp += (double)pl;
-      if (a.part_band) {
-        const double r = wave_sum((double)rowacc);
-        if (lane == 0) s_red[par][wv] = r;
-        pending = j;
-        par ^= 1;
-      }
-    }
-  }
-
-  if constexpr (PASS == 2) {
     __syncthreads();
     if (pending >= 0 && tid == 0) {
       double s = 0.0;
       for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
       a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
     }
-    T tot = T(0);
-    char* __restrict__ time_row =
-        reinterpret_cast<char*>(a.time_part ? a.time_part + ((int64_t)ch * gridDim.y + blockIdx.y) * a.n : nullptr);
+    cplx<T> u[32];
+    rows_fft1024<T, C>(buf, tw, u, QI_DBG(4));
+
+    const int64_t orow = ((int64_t)ch * a.nbands + j) * a.n;
+    char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+    char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    // the output offsets do not depend on the band; hide that from the optimiser, which would otherwise hoist
+    // every address out of the band loop and spill them
+    uint32_t tb = tbase;
+    asm volatile("" : "+v"(tb));
+    T rowacc = T(0), pl = T(0);
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      tot += col[i];
-      uint32_t tt = tbase + (uint32_t)i * tstep;
-      if (KIND == 0 && i == NOUT - 1 && edge) tt = 0;
-      if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = col[i];
+      const int c = KIND == 0 ? i + 8 : (KIND == 1 ? ((i + 16) & 31) : i);
+      const cplx<T> z = u[brev(c, 5)];
+      const uint32_t tt = tb + (uint32_t)i * tstep;
+      if (coef_row && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+      const T m2 = z.x * z.x + z.y * z.y;
+      if (bits_row) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
+      const T p = a.power_scale * m2;
+      col[i] += p;
+      if (!QI_DBG(8)) {
+        rowacc += p;
+        mx = p > mx ? p : mx;
+        pl += plog2p(p);
+      }
     }
-    if (a.part_stat) {
-      const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
-      if (lane == 0) {
-        s_fin[0][wv] = r0;
-        s_fin[1][wv] = r1;
-        s_fin[2][wv] = r2;
+    plogp += (double)pl;
+    if (a.part_band) {
+      const double r = wave_sum((double)rowacc);
+      if (lane == 0) s_red[par][wv] = r;
+      pending = j;
+      par ^= 1;
+    }
+  }
+
+  __syncthreads();
+  if (pending >= 0 && tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
+    a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
+  }
+  T tot = T(0);
+  char* __restrict__ time_row =
+      reinterpret_cast<char*>(a.time_part ? a.time_part + ((int64_t)ch * gridDim.y + blockIdx.y) * a.n : nullptr);
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    tot += col[i];
+    const uint32_t tt = tbase + (uint32_t)i * tstep;
+    if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = col[i];
+  }
+  if (a.part_stat) {
+    const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
+    if (lane == 0) {
+      s_fin[0][wv] = r0;
+      s_fin[1][wv] = r1;
+      s_fin[2][wv] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int w = 0; w < C::TH / kWave; ++w) {
+        m = s_fin[0][w] > m ? s_fin[0][w] : m;
+        s1 += s_fin[1][w];
+        s2 += s_fin[2][w];
       }
-      __syncthreads();
-      if (tid == 0) {
-        double m = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int w = 0; w < C::TH / kWave; ++w) {
-          m = s_fin[0][w] > m ? s_fin[0][w] : m;
-          s1 += s_fin[1][w];
-          s2 += s_fin[2][w];
-        }
-        double* o = a.part_stat + (((int64_t)ch * gridDim.y + blockIdx.y) * a.nblk + grp) * 3;
-        o[0] = m;
-        o[1] = s1;
-        o[2] = s2;
-      }
+      double* o = a.part_stat + (((int64_t)ch * gridDim.y + blockIdx.y) * a.nblk + grp) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
     }
   }
 }
@@ -516,61 +573,58 @@ __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict
     }                                                                                    \
   } while (0)
 
-template <typename T, class C, int PASS, int KIND>
-static int launch_rows(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
-  static bool configured = false;
-  auto kern = k_rows<T, C, PASS, KIND>;
-  if (!configured) {
+template <class Kern, typename T>
+static int launch_lds(Kern kern, bool* configured, size_t lds, const RowArgs<T>& a, dim3 grid, int threads,
+                      hipStream_t st) {
+  if (!*configured) {
     QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)C::LDS_BYTES));
-    configured = true;
+                               (int)lds));
+    *configured = true;
   }
-  kern<<<grid, C::TH, C::LDS_BYTES, st>>>(a);
+  kern<<<grid, threads, lds, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
 
-template <typename T, class C, int PASS>
-static int launch_rows_kind(const RowArgs<T>& a, int kind, dim3 grid, hipStream_t st) {
-  if (PASS == 1)  // pass 1 only distinguishes the Stockwell window from a stored bank row
-    return kind == 2 ? launch_rows<T, C, PASS, 2>(a, grid, st) : launch_rows<T, C, PASS, 0>(a, grid, st);
-  switch (kind) {
-    case 0: return launch_rows<T, C, PASS, 0>(a, grid, st);
-    case 1: return launch_rows<T, C, PASS, 1>(a, grid, st);
-    default: return launch_rows<T, C, PASS, 2>(a, grid, st);
-  }
+template <typename T, class C, bool STX, int NPH>
+static int launch_p1(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  return launch_lds(k_pass1<T, C, STX, NPH>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
+}
+template <typename T, class C, int KIND>
+static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
+  static bool configured = false;
+  return launch_lds(k_pass2<T, C, KIND>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
 }
 
 template <>
 int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
   if (a.ngen_launch <= 0) return QI_OK;
-  if (a.N1 == 1024) {
-    using C = Cfg<float, 32, 16, true>;
-    dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
-    return launch_rows_kind<float, C, 1>(a, kind, grid, st);
-  }
-  if (a.N1 == 2048) {
-    using C = Cfg<float, 64, 8, true>;
-    dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
-    return launch_rows_kind<float, C, 1>(a, kind, grid, st);
-  }
+  using C = Cfg<float, 16, true>;
+  dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
+  const bool stx = kind == 2;
+  if (a.N1 == 1024) return stx ? launch_p1<float, C, true, 1>(a, grid, st) : launch_p1<float, C, false, 1>(a, grid, st);
+  if (a.N1 == 2048) return stx ? launch_p1<float, C, true, 2>(a, grid, st) : launch_p1<float, C, false, 2>(a, grid, st);
   set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
   return QI_ERR_UNSUPPORTED;
+}
+
+template <class C>
+static int launch_pass2_cfg(const RowArgs<float>& a, int kind, int nchunk, int64_t n_channels, hipStream_t st) {
+  dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
+  switch (kind) {
+    case 0: return launch_p2<float, C, 0>(a, grid, st);
+    case 1: return launch_p2<float, C, 1>(a, grid, st);
+    default: return launch_p2<float, C, 2>(a, grid, st);
+  }
 }
 
 template <>
 int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
                         hipStream_t st) {
-  if (rows_per_group == 16) {
-    using C = Cfg<float, 32, 16, false>;
-    dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
-    return launch_rows_kind<float, C, 2>(a, kind, grid, st);
-  }
-  if (rows_per_group == 8) {  // half the LDS image: two workgroups per CU hide each other's barriers
-    using C = Cfg<float, 32, 8, false>;
-    dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
-    return launch_rows_kind<float, C, 2>(a, kind, grid, st);
-  }
+  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float, 16, false>>(a, kind, nchunk, n_channels, st);
+  // half the LDS image: two workgroups per CU hide each other's barriers
+  if (rows_per_group == 8) return launch_pass2_cfg<Cfg<float, 8, false>>(a, kind, nchunk, n_channels, st);
   set_error("pass 2 supports 8 or 16 rows per workgroup, got %d", rows_per_group);
   return QI_ERR_UNSUPPORTED;
 }

@@ -31,6 +31,7 @@ struct RowArgs {
   cplx<T>* imd;          // [C][ngen][N2][N1] intermediate of the general bands
   T inv_len;
   float two_over_len;  // 2 / Lf (exact)
+  int32_t neg_last_row;  // pass 1 of the linear kind: twiddle of t1 = N1 - 1 taken at t1 = -1
   // pass 2 outputs
   cplx<T>* coef;
   T* bits;
