@@ -200,12 +200,17 @@ struct qi_plan {
   FftCache fft;
   Profiler prof;
   // native engine: per transform kind (0 styx bank, 1 atoms bank, 2 Stockwell) the band descriptors
+  struct NativeGroup {  // bands launched together: their wide members share one intermediate buffer
+    int32_t first = 0, count = 0;    // range of d_bands
+    int32_t gen_first = 0, ngen = 0; // range of d_gen_list (indices relative to `first`)
+  };
   struct NativeTable {
     bool ready = false;
     int64_t Lf = 0;
-    int32_t nbands = 0, ngen = 0;
-    native::BandDesc* d_bands = nullptr;
+    int32_t nbands = 0, ngen = 0, imd_slots = 0;
+    native::BandDesc* d_bands = nullptr;  // grouped order
     int32_t* d_gen_list = nullptr;
+    std::vector<NativeGroup> groups;
     void* Hc = nullptr;
     void* Hfull = nullptr;
     void release() {
@@ -218,6 +223,7 @@ struct qi_plan {
   } nat[3];
   int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
   int native_debug = 0;
+  int native_group = 0;        // wide bands per launch group (0: all in one group)
   int native_rows = 16;        // consecutive time residues (rows) per pass-2 workgroup: 8 or 16
 };
 
@@ -361,20 +367,46 @@ bool native_wanted(const qi_plan* p, int kind) {
   return is_pow2(p->n) && native_len_ok(Lf);
 }
 
-int upload_native_table(qi_plan* p, int kind, int64_t Lf, const std::vector<native::BandDesc>& bands) {
+// Order the bands into launch groups: the wide bands are dealt out `native_group` per group (all in one group when
+// 0) so that a group's intermediate is small enough to stay in the last-level cache between pass 1 and pass 2; the
+// narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
+int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
+  std::vector<int32_t> wide, narrow;
+  for (size_t j = 0; j < bands.size(); ++j) (bands[j].mode == 1 ? wide : narrow).push_back((int32_t)j);
+  const int32_t per = p->native_group > 0 ? p->native_group : (int32_t)wide.size();
+  const int32_t ngroups = wide.empty() ? 1 : (int32_t)ceil_div((int64_t)wide.size(), per);
+  std::vector<native::BandDesc> ordered;
   std::vector<int32_t> gen;
-  for (size_t j = 0; j < bands.size(); ++j)
-    if (bands[j].mode == 1) gen.push_back((int32_t)j);
-  QI_HIP(hipMalloc((void**)&t.d_bands, bands.size() * sizeof(native::BandDesc)));
-  QI_HIP(hipMemcpy(t.d_bands, bands.data(), bands.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
+  t.groups.clear();
+  size_t wi = 0, ni = 0;
+  for (int32_t g = 0; g < ngroups; ++g) {
+    qi_plan::NativeGroup grp;
+    grp.first = (int32_t)ordered.size();
+    grp.gen_first = (int32_t)gen.size();
+    int32_t slot = 0;
+    for (int32_t q = 0; q < per && wi < wide.size(); ++q, ++wi) {
+      native::BandDesc d = bands[wide[wi]];
+      d.gen_slot = slot++;
+      gen.push_back((int32_t)ordered.size() - grp.first);
+      ordered.push_back(d);
+    }
+    const size_t share = (narrow.size() * (size_t)(g + 1)) / (size_t)ngroups;
+    for (; ni < share; ++ni) ordered.push_back(bands[narrow[ni]]);
+    grp.count = (int32_t)ordered.size() - grp.first;
+    grp.ngen = (int32_t)gen.size() - grp.gen_first;
+    if (grp.count > 0) t.groups.push_back(grp);
+  }
+  QI_HIP(hipMalloc((void**)&t.d_bands, ordered.size() * sizeof(native::BandDesc)));
+  QI_HIP(hipMemcpy(t.d_bands, ordered.data(), ordered.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
   if (!gen.empty()) {
     QI_HIP(hipMalloc((void**)&t.d_gen_list, gen.size() * sizeof(int32_t)));
     QI_HIP(hipMemcpy(t.d_gen_list, gen.data(), gen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   t.Lf = Lf;
   t.nbands = (int32_t)bands.size();
-  t.ngen = (int32_t)gen.size();
+  t.ngen = (int32_t)wide.size();
+  t.imd_slots = wide.empty() ? 0 : (per < (int32_t)wide.size() ? per : (int32_t)wide.size());
   t.ready = true;
   return QI_OK;
 }
@@ -420,6 +452,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipS
     memset(&d, 0, sizeof(d));
     const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
+    d.out_band = j;
     if (len > 0 && len <= p->native_kmax) {
       d.mode = 0;
       d.k_lo = (int32_t)lo;
@@ -428,7 +461,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipS
       compact += len;
     } else {
       d.mode = 1;
-      d.gen_slot = ngen++;
+      d.bank_row = ngen++;
     }
   }
   auto& t = p->nat[bank];
@@ -446,7 +479,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipS
                                               d.k_len, circular, 1.0 / (double)L, st));
       else
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
-                                              static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.gen_slot * L, 0, L, circular,
+                                              static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.bank_row * L, 0, L, circular,
                                               1.0 / (double)L, st));
     }
   }
@@ -462,20 +495,25 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const T* sig = static_cast<const T*>(sig_v);
   const int G = p->native_rows;
   const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
-  int nchunk = (int)ceil_div(512, nblk * C);
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > B) nchunk = (int)B;
-  const int bpc = (int)ceil_div(B, nchunk);
-  nchunk = (int)ceil_div(B, bpc);
+  // chunks (workgroups along the band list) per group: enough workgroups to fill the chip
+  std::vector<int> nchunk(t.groups.size());
+  int chunk_total = 0;
+  for (size_t g = 0; g < t.groups.size(); ++g) {
+    int nc = (int)ceil_div(512, nblk * C);
+    if (nc < 1) nc = 1;
+    if (nc > t.groups[g].count) nc = t.groups[g].count;
+    nchunk[g] = nc;
+    chunk_total += nc;
+  }
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
-  const bool time_via_part = want_time && nchunk > 1;
+  const bool time_via_part = want_time && chunk_total > 1;
   // scratch regions, each [Ct][...] without per-channel padding
   const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
-  const size_t e_imd = (size_t)t.ngen * Lf * sizeof(cplx<T>);
+  const size_t e_imd = (size_t)t.imd_slots * Lf * sizeof(cplx<T>);
   const size_t e_pb = (size_t)B * nblk * 8;
-  const size_t e_ps = (size_t)nchunk * nblk * 24;
-  const size_t e_tp = time_via_part ? (size_t)nchunk * n * sizeof(T) : 0;
+  const size_t e_ps = (size_t)chunk_total * nblk * 24;
+  const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
   const size_t per_chan = e_x + e_imd + e_pb + e_ps + e_tp;
   if (p->ws_bytes < per_chan + 2048) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
@@ -506,11 +544,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.n = n;
     a.N1 = N1;
     a.N2 = native::kN2;
-    a.nbands = (int32_t)B;
-    a.bands = t.d_bands;
-    a.gen_list = t.d_gen_list;
-    a.ngen = t.ngen;
-    a.ngen_launch = t.ngen;
+    a.panel_bands = (int32_t)B;
+    a.imd_slots = t.imd_slots;
+    a.chunk_total = chunk_total;
     a.X = X;
     a.Hc = static_cast<const cplx<T>*>(t.Hc);
     a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
@@ -525,25 +561,35 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     a.part_band = want_band ? part_band : nullptr;
     a.part_stat = want_stat ? part_stat : nullptr;
     a.nblk = nblk;
-    a.bands_per_chunk = bpc;
     a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
     a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
-    if (t.ngen > 0) {
+    int chunk_base = 0;
+    for (size_t g = 0; g < t.groups.size(); ++g) {
+      const auto& grp = t.groups[g];
+      a.bands = t.d_bands + grp.first;
+      a.nbands = grp.count;
+      a.gen_list = t.d_gen_list ? t.d_gen_list + grp.gen_first : nullptr;
+      a.ngen_launch = grp.ngen;
+      a.chunk_base = chunk_base;
+      if (grp.ngen > 0) {
+        p->prof.begin(st);
+        QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
+        p->prof.end(QI_STAGE_PASS1, st);
+      }
       p->prof.begin(st);
-      QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
-      p->prof.end(QI_STAGE_PASS1, st);
+      QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk[g], ct, st));
+      p->prof.end(QI_STAGE_PASS2, st);
+      chunk_base += nchunk[g];
     }
     p->prof.begin(st);
-    QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk, ct, st));
-    p->prof.end(QI_STAGE_PASS2, st);
-    p->prof.begin(st);
     if (time_via_part)
-      QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, nchunk, st));
+      QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
+                                           st));
     if (want_band || want_stat)
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nblk,
-                             (int64_t)nchunk * nblk, st));
+                             (int64_t)chunk_total * nblk, st));
     p->prof.end(QI_STAGE_EPILOGUE, st);
   }
   return QI_OK;
@@ -636,6 +682,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (p->native_kmax > (int64_t)native::kMaxPrunedTerms * native::kN2)
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
   if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_GROUP")) p->native_group = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -773,11 +820,13 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef
     std::vector<native::BandDesc> bands(B);
     int32_t ngen = 0;
+    (void)ngen;
     for (int32_t j = 0; j < B; ++j) {
       native::BandDesc& d = bands[j];
       memset(&d, 0, sizeof(d));
       d.shift = shift_index[j];
       d.coef = coef[j];
+      d.out_band = j;
       const double kh = std::floor(std::sqrt(30.0) / coef[j]);
       if (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n) {
         d.mode = 0;
@@ -785,7 +834,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
         d.k_len = 2 * (int32_t)kh + 1;
       } else {
         d.mode = 1;
-        d.gen_slot = ngen++;
+        ngen++;
       }
     }
     QI_TRY(upload_native_table(p, 2, p->n, bands));

@@ -206,7 +206,7 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
   constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
   static_assert(ITERS % BATCH == 0, "batch");
   const uint32_t mask = (uint32_t)a.Lf - 1u;
-  const cplx<T>* __restrict__ H = STX ? nullptr : a.Hfull + (int64_t)bd.gen_slot * a.Lf;
+  const cplx<T>* __restrict__ H = STX ? nullptr : a.Hfull + (int64_t)bd.bank_row * a.Lf;
 #pragma unroll 1
   for (int it = 0; it < ITERS; it += BATCH) {
     cplx<T> xs[BATCH], hs[BATCH];
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const uint32_t k2 = row0 + g2;
   // The linear kind's pass 2 works on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken
   // at -1): columns are stored at r = (t1 + 1) mod N1 so that pass 2 reads aligned runs of G columns.
-  cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.ngen + bd.gen_slot) * a.N2 + k2) * a.N1;
+  cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.imd_slots + bd.gen_slot) * a.N2 + k2) * a.N1;
   const uint32_t roll = a.neg_last_row ? 1u : 0u, cmask = (uint32_t)a.N1 - 1u;
   // pass twiddle W_Lf^(k2 t1) along t1 = d2 + 32 c by a float64 recurrence from single-precision seeds
   double wr, wi, sr, si;
@@ -402,26 +402,27 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
   int par = 0;
 
-  // bands blockIdx.y, blockIdx.y + nchunk, ...: every chunk gets the same mix of narrow and wide bands
-  for (int64_t j = blockIdx.y; j < a.nbands; j += gridDim.y) {
-    const BandDesc bd = a.bands[j];
+  // list entries blockIdx.y, blockIdx.y + nchunk, ...: every chunk gets the same mix of narrow and wide bands
+  for (int64_t jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
+    const BandDesc bd = a.bands[jj];
+    const int64_t j = bd.out_band;  // row of the panel this band writes
     if (!QI_DBG(2)) {
       if (bd.mode == 0)
         load_pruned<T, C, STX>(buf, a, bd, Xc, t1_first);
       else
-        load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.ngen + bd.gen_slot) * a.Lf, (uint32_t)a.N1, row0);
+        load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.imd_slots + bd.gen_slot) * a.Lf, (uint32_t)a.N1, row0);
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (pending >= 0 && tid == 0) {
       double s = 0.0;
       for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
-      a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
+      a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + grp] = s;
     }
     cplx<T> u[32];
     rows_fft1024<T, C>(buf, tw, u, QI_DBG(4));
 
-    const int64_t orow = ((int64_t)ch * a.nbands + j) * a.n;
+    const int64_t orow = ((int64_t)ch * a.panel_bands + j) * a.n;
     char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
     char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
     // the output offsets do not depend on the band; hide that from the optimiser, which would otherwise hoist
@@ -458,11 +459,12 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   if (pending >= 0 && tid == 0) {
     double s = 0.0;
     for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
-    a.part_band[((int64_t)ch * a.nbands + pending) * a.nblk + grp] = s;
+    a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + grp] = s;
   }
   T tot = T(0);
   char* __restrict__ time_row =
-      reinterpret_cast<char*>(a.time_part ? a.time_part + ((int64_t)ch * gridDim.y + blockIdx.y) * a.n : nullptr);
+      reinterpret_cast<char*>(a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * a.n
+                                          : nullptr);
 #pragma unroll
   for (int i = 0; i < NOUT; ++i) {
     tot += col[i];
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
         s1 += s_fin[1][w];
         s2 += s_fin[2][w];
       }
-      double* o = a.part_stat + (((int64_t)ch * gridDim.y + blockIdx.y) * a.nblk + grp) * 3;
+      double* o = a.part_stat + (((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * a.nblk + grp) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;

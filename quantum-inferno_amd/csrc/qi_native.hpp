@@ -12,7 +12,9 @@ struct BandDesc {
   int32_t mode;      // 0: pruned (spectrum support short enough for the one-pass loader), 1: general
   int32_t k_lo;      // first bin of the support (negative for the Stockwell window, centred on 0)
   int32_t k_len;     // number of support bins
-  int32_t gen_slot;  // general bands: row in the intermediate / in the full-row bank
+  int32_t gen_slot;  // general bands: slot of the intermediate buffer used by its launch group
+  int32_t out_band;  // row of the panel this band writes
+  int32_t bank_row;  // general Gabor bands: row of the full-spectrum bank
   int64_t src_off;   // pruned Gabor bands: offset of H[k_lo] in the compact bank
   int64_t shift;     // Stockwell: shift index idx_j
   double coef;       // Stockwell: window coefficient (exp2(-(coef k)^2))
@@ -21,23 +23,25 @@ struct BandDesc {
 template <typename T>
 struct RowArgs {
   int64_t Lf, n, N1, N2;
-  int32_t nbands;
-  const BandDesc* bands;    // [nbands] device
-  const int32_t* gen_list;  // [ngen] band ids of the general bands (pass 1 launch order)
-  int32_t ngen, ngen_launch;
+  int32_t nbands;           // entries of `bands` handled by this launch
+  int32_t panel_bands;      // bands of the whole panel (row stride of the outputs)
+  const BandDesc* bands;    // [nbands] device: the launch group's band list
+  const int32_t* gen_list;  // [ngen_launch] indices into `bands` of its general bands (pass 1 launch order)
+  int32_t ngen_launch, imd_slots;
+  int32_t chunk_base, chunk_total;  // this launch owns chunks [chunk_base, chunk_base + gridDim.y) of chunk_total
   const cplx<T>* X;      // [C][Lf] spectra of the records
   const cplx<T>* Hc;     // compact bank of the pruned Gabor bands
   const cplx<T>* Hfull;  // [ngen][Lf] full spectra of the general Gabor bands
-  cplx<T>* imd;          // [C][ngen][N2][N1] intermediate of the general bands
+  cplx<T>* imd;          // [C][imd_slots][N2][N1] intermediate of the launch group's general bands
   T inv_len;
   float two_over_len;  // 2 / Lf (exact)
   int32_t neg_last_row;  // pass 1 of the linear kind: twiddle of t1 = N1 - 1 taken at t1 = -1
   // pass 2 outputs
   cplx<T>* coef;
   T* bits;
-  T* time_part;       // [C][nchunk][n]
-  double* part_band;  // [C][nbands][nblk]
-  double* part_stat;  // [C][nchunk][nblk][3]
+  T* time_part;       // [C][chunk_total][n]
+  double* part_band;  // [C][panel_bands][nblk]
+  double* part_stat;  // [C][chunk_total][nblk][3]
   int64_t nblk;       // N1 / G
   int32_t bands_per_chunk;
   T power_scale, eps;
