@@ -220,7 +220,11 @@ struct qi_plan {
       if (Hfull) (void)hipFree(Hfull);
       *this = NativeTable();
     }
-  } nat[3];
+  } nat[4];  // 0 styx bank (linear, Lf = 2n), 1 atoms bank (circular), 2 Stockwell, 3 styx short-atom bands (circular n)
+  native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
+  int32_t nedge = 0;
+  int64_t edge_wmax = 0;
+  int native_short = 1;  // evaluate short-atom styx bands circularly at length n (0: everything at 2n)
   int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
   int native_debug = 0;
   int native_group = 0;        // wide bands per launch group (0: all in one group)
@@ -411,48 +415,83 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
   return QI_OK;
 }
 
-// Native bank: analyse the support of every atom spectrum, keep a compact window for the narrow ones and
-// the full row for the wide ones (two sweeps over the float64 rows so that only one chunk is resident).
-template <typename T>
-int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipStream_t st) {
-  const int64_t n = p->n;
-  const int circular = bank == QI_BANK_ATOMS;
-  const int64_t L = circular ? n : p->L;
+// Support analysis of `count` atom spectra starting at band j0 (rows built in `circular` or linear form).
+int analyse_support(qi_plan* p, int circular, int64_t L, int32_t B, int32_t j0, int32_t count, const double* d_par,
+                    std::vector<double>* sup, hipStream_t st) {
   const size_t row64 = (size_t)L * sizeof(double2);
   int64_t chunk = (int64_t)((p->ws_bytes - 4096) / row64);
   if (chunk < 1) {
     set_error("workspace too small to build one bank row (%zu bytes needed)", row64);
     return QI_ERR_NOMEM;
   }
-  if (chunk > B) chunk = B;
   double2* rows = reinterpret_cast<double2*>(p->ws);
   double* d_sup = nullptr;
-  QI_HIP(hipMalloc((void**)&d_sup, (size_t)B * 3 * sizeof(double)));
+  QI_HIP(hipMalloc((void**)&d_sup, (size_t)count * 3 * sizeof(double)));
   const double thr2 = std::ldexp(1.0, -60);  // |H| below 2^-30 of the row maximum is dropped
   int rc = QI_OK;
-  for (int32_t j0 = 0; j0 < B && rc == QI_OK; j0 += (int32_t)chunk) {
-    const int nbk = (B - j0 < chunk) ? B - j0 : (int)chunk;
-    rc = launch_bank_rows(rows, n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0, nbk, st);
+  for (int32_t q = 0; q < count && rc == QI_OK; q += (int32_t)chunk) {
+    const int nbk = (count - q < chunk) ? count - q : (int)chunk;
+    rc = launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0 + q, nbk, st);
     if (rc == QI_OK) rc = fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st);
-    if (rc == QI_OK) rc = native::launch_band_support(rows, L, nbk, thr2, d_sup + (size_t)j0 * 3, st);
+    if (rc == QI_OK) rc = native::launch_band_support(rows, L, nbk, thr2, d_sup + (size_t)q * 3, st);
   }
-  std::vector<double> sup((size_t)B * 3);
+  sup->assign((size_t)count * 3, 0.0);
   if (rc == QI_OK && (hipStreamSynchronize(st) != hipSuccess ||
-                      hipMemcpy(sup.data(), d_sup, sup.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) {
+                      hipMemcpy(sup->data(), d_sup, sup->size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) {
     set_error("support analysis failed: %s", hipGetErrorString(hipGetLastError()));
     rc = QI_ERR_HIP;
   }
   (void)hipFree(d_sup);
-  QI_TRY(rc);
-  std::vector<native::BandDesc> bands(B);
+  return rc;
+}
+
+// Fill the compact / full-row banks of table `t` for the bands listed in `ids` (global band ids; descriptors in
+// `bands`, same order) from freshly built float64 spectra.
+template <typename T>
+int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t L, int32_t B,
+                     const std::vector<int32_t>& ids, const std::vector<native::BandDesc>& bands, const double* d_par,
+                     hipStream_t st) {
+  const size_t row64 = (size_t)L * sizeof(double2);
+  int64_t chunk = (int64_t)((p->ws_bytes - 4096) / row64);
+  double2* rows = reinterpret_cast<double2*>(p->ws);
+  size_t q = 0;
+  while (q < ids.size()) {
+    // a run of consecutive band ids, at most `chunk` long
+    size_t r = q + 1;
+    while (r < ids.size() && ids[r] == ids[r - 1] + 1 && (int64_t)(r - q) < chunk) ++r;
+    const int nbk = (int)(r - q);
+    QI_TRY(launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, ids[q], nbk, st));
+    QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
+    for (int jj = 0; jj < nbk; ++jj) {
+      const native::BandDesc& d = bands[q + jj];
+      if (d.mode == 0)
+        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
+                                              d.k_len, circular, 1.0 / (double)L, st));
+      else
+        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
+                                              static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.bank_row * L, 0, L, circular,
+                                              1.0 / (double)L, st));
+    }
+    q = r;
+  }
+  return QI_OK;
+}
+
+// Classify bands by spectrum support, allocate and fill one table.
+template <typename T>
+int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B, const std::vector<int32_t>& ids,
+                      const std::vector<double>& sup /*[ids][3]*/, const std::vector<int32_t>& edge_w,
+                      const double* d_par, hipStream_t st) {
+  std::vector<native::BandDesc> bands(ids.size());
   int64_t compact = 0;
   int32_t ngen = 0;
-  for (int32_t j = 0; j < B; ++j) {
-    native::BandDesc& d = bands[j];
+  for (size_t q = 0; q < ids.size(); ++q) {
+    native::BandDesc& d = bands[q];
     memset(&d, 0, sizeof(d));
-    const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
+    const int64_t lo = (int64_t)sup[3 * q + 1], hi = (int64_t)sup[3 * q + 2];
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
-    d.out_band = j;
+    d.out_band = ids[q];
+    d.edge = edge_w.empty() ? 0 : edge_w[q];
     if (len > 0 && len <= p->native_kmax) {
       d.mode = 0;
       d.k_lo = (int32_t)lo;
@@ -464,132 +503,244 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipS
       d.bank_row = ngen++;
     }
   }
-  auto& t = p->nat[bank];
+  auto& t = p->nat[table];
   t.release();
+  if (ids.empty()) return QI_OK;
   if (compact > 0) QI_HIP(hipMalloc(&t.Hc, (size_t)compact * sizeof(cplx<T>)));
   if (ngen > 0) QI_HIP(hipMalloc(&t.Hfull, (size_t)ngen * L * sizeof(cplx<T>)));
-  for (int32_t j0 = 0; j0 < B; j0 += (int32_t)chunk) {
-    const int nbk = (B - j0 < chunk) ? B - j0 : (int)chunk;
-    QI_TRY(launch_bank_rows(rows, n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0, nbk, st));
-    QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
-    for (int jj = 0; jj < nbk; ++jj) {
-      const native::BandDesc& d = bands[j0 + jj];
-      if (d.mode == 0)
-        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
-                                              d.k_len, circular, 1.0 / (double)L, st));
-      else
-        QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
-                                              static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.bank_row * L, 0, L, circular,
-                                              1.0 / (double)L, st));
-    }
-  }
-  return upload_native_table(p, bank, L, bands);
+  QI_TRY(fill_native_bank<T>(p, t, circular, L, B, ids, bands, d_par, st));
+  return upload_native_table(p, table, L, bands);
 }
 
-// One transform on the native engine: forward FFT of the records (hipFFT), pass 1 for the wide bands,
-// pass 2 with the fused epilogue for every band, fixed-order finalisation of the reductions.
+// Native bank.  Every atom spectrum is analysed for its support: a narrow one keeps a compact window (one-pass
+// "pruned" bands), a wide one its full row.  For the styx bank (zero-padded linear correlation, Lf = 2n) a band whose
+// spectrum is wide but whose ATOM is short in time is not run at 2n at all: it is evaluated as a circular
+// correlation of length n (half the bank row, half the intermediate, no discarded outputs) and its first / last W
+// samples -- the only ones where circular and linear differ -- are corrected by k_edge_fix.
+template <typename T>
+int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, const double* h_par, hipStream_t st) {
+  const int64_t n = p->n;
+  const int circular = bank == QI_BANK_ATOMS;
+  const int64_t L = circular ? n : p->L;
+  std::vector<double> sup;
+  QI_TRY(analyse_support(p, circular, L, B, 0, B, d_par, &sup, st));
+  std::vector<int32_t> keep, shorts, short_w;
+  const bool can_short = !circular && p->native_short && native_len_ok(n) && is_pow2(n);
+  for (int32_t j = 0; j < B; ++j) {
+    const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
+    const int64_t len = hi >= lo ? hi - lo + 1 : 0;
+    // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30
+    const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
+    if (can_short && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 && w < (double)n / 8) {
+      shorts.push_back(j);
+      short_w.push_back((int32_t)w);
+    } else {
+      keep.push_back(j);
+    }
+  }
+  std::vector<double> sup_keep;
+  for (int32_t j : keep) sup_keep.insert(sup_keep.end(), sup.begin() + 3 * j, sup.begin() + 3 * j + 3);
+  QI_TRY(make_native_table<T>(p, bank, circular, L, B, keep, sup_keep, {}, d_par, st));
+  p->nat[bank].nbands = B;  // the table's panel has all B rows even when some are produced by table 3
+  if (bank == QI_BANK_STYX) {
+    p->nat[3].release();
+    if (p->d_edge) (void)hipFree(p->d_edge);
+    p->d_edge = nullptr;
+    p->nedge = 0;
+    p->edge_wmax = 0;
+    if (!shorts.empty()) {
+      // spectra of the circular (length n) form of the short atoms
+      std::vector<double> sup_s((size_t)shorts.size() * 3);
+      size_t q = 0;
+      while (q < shorts.size()) {
+        size_t r = q + 1;
+        while (r < shorts.size() && shorts[r] == shorts[r - 1] + 1) ++r;
+        std::vector<double> part;
+        QI_TRY(analyse_support(p, 1, n, B, shorts[q], (int32_t)(r - q), d_par, &part, st));
+        std::copy(part.begin(), part.end(), sup_s.begin() + 3 * q);
+        q = r;
+      }
+      QI_TRY(make_native_table<T>(p, 3, 1, n, B, shorts, sup_s, short_w, d_par, st));
+      p->nat[3].nbands = B;
+      std::vector<native::EdgeBand> eb(shorts.size());
+      for (size_t i = 0; i < shorts.size(); ++i) {
+        const int32_t j = shorts[i];
+        eb[i].out_band = j;
+        eb[i].w = short_w[i];
+        eb[i].p_re = h_par[j];
+        eb[i].p_im = h_par[B + j];
+        eb[i].omega = h_par[2 * B + j];
+        eb[i].amp = h_par[3 * B + j];
+        if (short_w[i] > p->edge_wmax) p->edge_wmax = short_w[i];
+      }
+      QI_HIP(hipMalloc((void**)&p->d_edge, eb.size() * sizeof(native::EdgeBand)));
+      QI_HIP(hipMemcpy(p->d_edge, eb.data(), eb.size() * sizeof(native::EdgeBand), hipMemcpyHostToDevice));
+      p->nedge = (int32_t)eb.size();
+    }
+  }
+  return QI_OK;
+}
+
+// One transform on the native engine: forward FFT of the records (hipFFT), then per table (the styx bank has two:
+// the 2n-point linear part and the n-point circular part for short atoms) pass 1 for the wide bands and pass 2 with
+// the fused epilogue for every band, the edge correction of the short-atom bands, and a fixed-order finalisation of
+// the reductions.
 template <typename T>
 int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
-  const auto& t = p->nat[kind];
-  const int64_t n = p->n, Lf = t.Lf, B = t.nbands;
+  struct Sub {
+    const qi_plan::NativeTable* t;
+    int kernel_kind;
+    int64_t N1, nblk;
+    std::vector<int> nchunk;
+  };
+  std::vector<Sub> subs;
+  subs.push_back({&p->nat[kind], kind, 0, 0, {}});
+  const bool shorts = kind == 0 && p->nat[3].ready && p->nedge > 0;
+  if (shorts) subs.push_back({&p->nat[3], 1, 0, 0, {}});
+  const int64_t n = p->n, B = p->nat[kind].nbands, Lf0 = p->nat[kind].Lf;
+  if (shorts && !out->coef) {
+    set_error("native styx CWT: the coefficient panel is required (short-atom bands are corrected in place)");
+    return QI_ERR_UNSUPPORTED;
+  }
   const T* sig = static_cast<const T*>(sig_v);
   const int G = p->native_rows;
-  const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
-  // chunks (workgroups along the band list) per group: enough workgroups to fill the chip
-  std::vector<int> nchunk(t.groups.size());
+  int64_t nblk_max = 0, imd_elems = 0;
   int chunk_total = 0;
-  for (size_t g = 0; g < t.groups.size(); ++g) {
-    int nc = (int)ceil_div(512, nblk * C);
-    if (nc < 1) nc = 1;
-    if (nc > t.groups[g].count) nc = t.groups[g].count;
-    nchunk[g] = nc;
-    chunk_total += nc;
+  for (auto& sb : subs) {
+    sb.N1 = sb.t->Lf / native::kN2;
+    sb.nblk = sb.N1 / G;
+    if (sb.nblk > nblk_max) nblk_max = sb.nblk;
+    if ((int64_t)sb.t->imd_slots * sb.t->Lf > imd_elems) imd_elems = (int64_t)sb.t->imd_slots * sb.t->Lf;
+    for (const auto& grp : sb.t->groups) {
+      // chunks (workgroups along the band list): enough workgroups to fill the chip
+      int nc = (int)ceil_div(512, sb.nblk * C);
+      if (nc < 1) nc = 1;
+      if (nc > grp.count) nc = grp.count;
+      sb.nchunk.push_back(nc);
+      chunk_total += nc;
+    }
   }
+  const int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
+  const int64_t stat_slots = (int64_t)chunk_total * nbk + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
-  const bool time_via_part = want_time && chunk_total > 1;
+  const bool time_via_part = want_time && (chunk_total > 1 || shorts);
+  const bool clear_parts = subs.size() > 1;
   // scratch regions, each [Ct][...] without per-channel padding
-  const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
-  const size_t e_imd = (size_t)t.imd_slots * Lf * sizeof(cplx<T>);
-  const size_t e_pb = (size_t)B * nblk * 8;
-  const size_t e_ps = (size_t)chunk_total * nblk * 24;
+  const size_t e_x = (size_t)Lf0 * sizeof(cplx<T>);
+  const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
+  const size_t e_imd = (size_t)imd_elems * sizeof(cplx<T>);
+  const size_t e_pb = (size_t)B * nbk * 8;
+  const size_t e_ps = (size_t)stat_slots * 24;
   const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
-  const size_t per_chan = e_x + e_imd + e_pb + e_ps + e_tp;
-  if (p->ws_bytes < per_chan + 2048) {
+  const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
+  const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
+  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et;
+  if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
-              per_chan + 2048);
+              per_chan + 4096);
     return QI_ERR_NOMEM;
   }
-  int64_t Ct = (int64_t)((p->ws_bytes - 2048) / per_chan);
+  int64_t Ct = (int64_t)((p->ws_bytes - 4096) / per_chan);
   if (Ct > C) Ct = C;
   char* w = p->ws;
-  cplx<T>* X = reinterpret_cast<cplx<T>*>(w);
-  w += align_up(e_x * Ct);
-  cplx<T>* imd = reinterpret_cast<cplx<T>*>(w);
-  w += align_up(e_imd * Ct);
-  double* part_band = reinterpret_cast<double*>(w);
-  w += align_up(e_pb * Ct);
-  double* part_stat = reinterpret_cast<double*>(w);
-  w += align_up(e_ps * Ct);
-  T* time_part = reinterpret_cast<T*>(w);
+  auto carve = [&](size_t bytes) {
+    char* r = w;
+    w += align_up(bytes * Ct);
+    return r;
+  };
+  cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
+  cplx<T>* Xn = reinterpret_cast<cplx<T>*>(carve(e_xn));
+  cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
+  char* parts0 = w;
+  double* part_band = reinterpret_cast<double*>(carve(e_pb));
+  double* part_stat = reinterpret_cast<double*>(carve(e_ps));
+  const size_t parts_bytes = (size_t)(w - parts0);
+  T* time_part = reinterpret_cast<T*>(carve(e_tp));
+  T* edge_p = reinterpret_cast<T*>(carve(e_ep));
+  T* edge_time = reinterpret_cast<T*>(carve(e_et));
 
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
     p->prof.begin(st);
-    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
-    QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf0, st));
+    QI_TRY(fft_c2c<T>(p->fft, X, Lf0, ct, HIPFFT_FORWARD, st));
+    if (shorts) QI_TRY(native::launch_even_bins<T>(X, Xn, ct, n, st));
+    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.end(QI_STAGE_FORWARD, st);
-    native::RowArgs<T> a{};
-    a.Lf = Lf;
-    a.n = n;
-    a.N1 = N1;
-    a.N2 = native::kN2;
-    a.panel_bands = (int32_t)B;
-    a.imd_slots = t.imd_slots;
-    a.chunk_total = chunk_total;
-    a.X = X;
-    a.Hc = static_cast<const cplx<T>*>(t.Hc);
-    a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
-    a.imd = imd;
-    a.inv_len = (T)(1.0 / (double)Lf);
-    a.two_over_len = (float)(2.0 / (double)Lf);
-    a.debug = p->native_debug;
-    a.neg_last_row = kind == 0 ? 1 : 0;
-    a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
-    a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
-    a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
-    a.part_band = want_band ? part_band : nullptr;
-    a.part_stat = want_stat ? part_stat : nullptr;
-    a.nblk = nblk;
-    a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
-    a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
     int chunk_base = 0;
-    for (size_t g = 0; g < t.groups.size(); ++g) {
-      const auto& grp = t.groups[g];
-      a.bands = t.d_bands + grp.first;
-      a.nbands = grp.count;
-      a.gen_list = t.d_gen_list ? t.d_gen_list + grp.gen_first : nullptr;
-      a.ngen_launch = grp.ngen;
-      a.chunk_base = chunk_base;
-      if (grp.ngen > 0) {
+    for (size_t si = 0; si < subs.size(); ++si) {
+      const Sub& sb = subs[si];
+      const auto& t = *sb.t;
+      native::RowArgs<T> a{};
+      a.Lf = t.Lf;
+      a.n = n;
+      a.N1 = sb.N1;
+      a.N2 = native::kN2;
+      a.panel_bands = (int32_t)B;
+      a.imd_slots = t.imd_slots;
+      a.chunk_total = chunk_total;
+      a.X = si == 0 ? X : Xn;
+      a.Hc = static_cast<const cplx<T>*>(t.Hc);
+      a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
+      a.imd = imd;
+      a.inv_len = (T)(1.0 / (double)t.Lf);
+      a.two_over_len = (float)(2.0 / (double)t.Lf);
+      a.debug = p->native_debug;
+      a.neg_last_row = sb.kernel_kind == 0 ? 1 : 0;
+      a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+      a.part_band = want_band ? part_band : nullptr;
+      a.part_stat = want_stat ? part_stat : nullptr;
+      a.nblk = nbk;
+      a.stat_stride = stat_slots;
+      a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      for (size_t g = 0; g < t.groups.size(); ++g) {
+        const auto& grp = t.groups[g];
+        a.bands = t.d_bands + grp.first;
+        a.nbands = grp.count;
+        a.gen_list = t.d_gen_list ? t.d_gen_list + grp.gen_first : nullptr;
+        a.ngen_launch = grp.ngen;
+        a.chunk_base = chunk_base;
+        if (grp.ngen > 0) {
+          p->prof.begin(st);
+          QI_TRY(native::launch_pass1<T>(a, sb.kernel_kind, ct, st));
+          p->prof.end(QI_STAGE_PASS1, st);
+        }
         p->prof.begin(st);
-        QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
-        p->prof.end(QI_STAGE_PASS1, st);
+        QI_TRY(native::launch_pass2<T>(a, sb.kernel_kind, G, sb.nchunk[g], ct, st));
+        p->prof.end(QI_STAGE_PASS2, st);
+        chunk_base += sb.nchunk[g];
       }
-      p->prof.begin(st);
-      QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk[g], ct, st));
-      p->prof.end(QI_STAGE_PASS2, st);
-      chunk_base += nchunk[g];
     }
     p->prof.begin(st);
+    if (shorts) {
+      native::EdgeArgs<T> e{};
+      e.bands = p->d_edge;
+      e.nedge = p->nedge;
+      e.panel_bands = (int32_t)B;
+      e.n = n;
+      e.wmax = p->edge_wmax;
+      e.stat_slots = stat_slots;
+      e.sig = sig + c0 * n;
+      e.coef = static_cast<cplx<T>*>(out->coef) + c0 * B * n;
+      e.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      e.edge_p = edge_p;
+      e.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      e.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      QI_TRY(native::launch_edge<T>(e, ct, want_time ? edge_time : nullptr, want_band ? part_band : nullptr, nbk,
+                                    nbk - 1, want_stat ? part_stat : nullptr, stat_slots - p->nedge, st));
+    }
     if (time_via_part)
       QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
-                                           st));
+                                           shorts ? edge_time : nullptr, p->edge_wmax, st));
     if (want_band || want_stat)
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
-                             want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nblk,
-                             (int64_t)chunk_total * nblk, st));
+                             want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nbk, stat_slots,
+                             st));
     p->prof.end(QI_STAGE_EPILOGUE, st);
   }
   return QI_OK;
@@ -683,6 +834,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
   if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
   if (const char* e = getenv("QI_NATIVE_GROUP")) p->native_group = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -704,6 +856,7 @@ int qi_plan_destroy(qi_plan* p) {
   p->fft.clear();
   p->prof.clear();
   for (auto& t : p->nat) t.release();
+  if (p->d_edge) (void)hipFree(p->d_edge);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);
@@ -751,7 +904,7 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
   }
   if (rc == QI_OK) {
     if (use_native)
-      rc = build_native_bank<float>(p, bank, B, d_par, st);
+      rc = build_native_bank<float>(p, bank, B, d_par, host.data(), st);
     else
       rc = p->d.dtype == QI_F64 ? build_bank<double>(p, bank, B, d_par, st) : build_bank<float>(p, bank, B, d_par, st);
   }

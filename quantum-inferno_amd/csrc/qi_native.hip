@@ -438,7 +438,13 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       if (coef_row && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
       const T m2 = z.x * z.x + z.y * z.y;
       if (bits_row) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
-      const T p = a.power_scale * m2;
+      T p = a.power_scale * m2;
+      if (KIND == 1) {
+        // short-atom bands evaluated circularly: the first / last `edge` samples are corrected (and reduced) by
+        // k_edge_fix afterwards, so they are left out of the sums here.  edge = 0 keeps every sample.
+        const bool inside = (uint32_t)(tt - (uint32_t)bd.edge) < (uint32_t)(a.n - 2 * (int64_t)bd.edge);
+        p = inside ? p : T(0);
+      }
       col[i] += p;
       if (!QI_DBG(8)) {
         rowacc += p;
@@ -486,7 +492,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
         s1 += s_fin[1][w];
         s2 += s_fin[2][w];
       }
-      double* o = a.part_stat + (((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * a.nblk + grp) * 3;
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.nblk + grp) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;
@@ -494,14 +500,129 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   }
 }
 
-// power_time[c][t] = sum over chunks of time_part[c][q][t]
+// power_time[c][t] = sum over chunks of time_part[c][q][t] (+ the corrected edge samples of the short-atom bands)
 template <typename T>
-__global__ void k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk) {
+__global__ void k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
+                              const T* __restrict__ edge_time, int64_t wmax) {
   const int64_t c = blockIdx.y;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     T s = T(0);
     for (int q = 0; q < nchunk; ++q) s += part[(c * nchunk + q) * n + t];
+    if (edge_time) {
+      if (t < wmax) s += edge_time[(c * 2 + 0) * wmax + t];
+      if (t >= n - wmax) s += edge_time[(c * 2 + 1) * wmax + (n - 1 - t)];
+    }
     out[c * n + t] = s;
+  }
+}
+
+// Xn[c][k] = X2n[c][2k]: the n-point spectrum of a record is the even bins of its zero-padded 2n-point spectrum
+template <typename T>
+__global__ void k_even_bins(const cplx<T>* __restrict__ x2, cplx<T>* __restrict__ x1, int64_t n) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (k < n) x1[c * n + k] = x2[c * 2 * n + 2 * k];
+}
+
+// Edge correction of the short-atom bands that pass 2 evaluated as a circular correlation of length n: the
+// reference's zero-padded (linear) correlation differs only in the first / last W samples, by the taps that wrapped
+// around the record end.  One wave per output sample subtracts sum_m sig[m] conj(psi(u)) over the wrapped taps,
+// psi(u) = amp exp(-(p_re + i p_im) x^2) exp(i omega x), x = u + 1/2 (the centred atom of styx_cwt.py:113-144),
+// rewrites the coefficient (and bits) and leaves its power in edge_p for the fixed-order reduction below.
+template <typename T>
+__global__ void __launch_bounds__(256) k_edge_fix(EdgeArgs<T> a) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int64_t e = blockIdx.y, c = blockIdx.z;
+  const EdgeBand eb = a.bands[e];
+  const int64_t o = (int64_t)blockIdx.x * (256 / kWave) + wv;
+  const int side = o >= a.wmax ? 1 : 0;
+  const int64_t tloc = o - (int64_t)side * a.wmax;
+  if (tloc >= eb.w) return;
+  const int64_t cnt = eb.w - tloc;                      // wrapped taps of this output
+  const int64_t t = side ? a.n - 1 - tloc : tloc;       // output sample
+  const T* __restrict__ sig = a.sig + c * a.n;
+  T sr = T(0), si = T(0);
+  for (int64_t i = lane; i < cnt; i += kWave) {
+    // head: m = n - W + t + i, u = m - t - n = i - W;  tail: m = i, u = m - t + n = i + 1 + tloc
+    const int64_t m = side ? i : a.n - eb.w + t + i;
+    const double x = (side ? (double)(i + 1 + tloc) : (double)(i - eb.w)) + 0.5;
+    const double ph = eb.omega * x - eb.p_im * x * x;
+    const double turns = ph * 0.15915494309189535;  // / 2 pi
+    const float frac = (float)(turns - rint(turns));
+    float sn, cs;
+    sincospif(2.0f * frac, &sn, &cs);
+    const float env = (float)eb.amp * expf(-(float)(eb.p_re * x * x));
+    const T v = sig[m] * (T)env;
+    sr += v * (T)cs;   // sig * conj(psi): conj(e^{i ph}) = cos - i sin
+    si -= v * (T)sn;
+  }
+  sr = wave_sum(sr);
+  si = wave_sum(si);
+  if (lane == 0) {
+    const int64_t row = (c * a.panel_bands + eb.out_band) * a.n;
+    cplx<T> z = a.coef[row + t];
+    z.x -= sr;
+    z.y -= si;
+    a.coef[row + t] = z;
+    const T m2 = z.x * z.x + z.y * z.y;
+    if (a.bits) a.bits[row + t] = log2_t(sqrt_t(m2) + a.eps);
+    a.edge_p[((c * a.nedge + e) * 2 + side) * a.wmax + tloc] = a.power_scale * m2;
+  }
+}
+
+// Fixed-order reduction of the corrected edge powers.  Workgroup (e, c) with e < nedge: the edge samples of band e
+// -> one extra partial of part_band and one extra part_stat entry; workgroups e >= nedge: per-sample sums over the
+// bands -> edge_time.
+template <typename T>
+__global__ void __launch_bounds__(256) k_edge_reduce(EdgeArgs<T> a, T* __restrict__ edge_time,
+                                                     double* __restrict__ part_band, int64_t nblk, int64_t band_slot,
+                                                     double* __restrict__ part_stat, int64_t stat_slot0) {
+  __shared__ double s[3][256 / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int64_t c = blockIdx.y;
+  const T* __restrict__ ep = a.edge_p + c * a.nedge * 2 * a.wmax;
+  if ((int64_t)blockIdx.x >= a.nedge) {
+    if (!edge_time) return;
+    const int64_t i = ((int64_t)blockIdx.x - a.nedge) * 256 + tid;
+    if (i >= 2 * a.wmax) return;
+    const int side = i >= a.wmax ? 1 : 0;
+    const int64_t tloc = i - (int64_t)side * a.wmax;
+    T r = T(0);
+    for (int64_t e = 0; e < a.nedge; ++e)
+      if (tloc < a.bands[e].w) r += ep[(e * 2 + side) * a.wmax + tloc];
+    edge_time[(c * 2 + side) * a.wmax + tloc] = r;
+    return;
+  }
+  const int64_t e = blockIdx.x, w = a.bands[e].w;
+  double mx = 0.0, sum = 0.0, pl = 0.0;
+  for (int64_t i = tid; i < 2 * w; i += 256) {
+    const double p = (double)ep[(e * 2 + (i >= w ? 1 : 0)) * a.wmax + (i >= w ? i - w : i)];
+    sum += p;
+    mx = p > mx ? p : mx;
+    pl += (double)plog2p((T)p);
+  }
+  mx = wave_max(mx);
+  sum = wave_sum(sum);
+  pl = wave_sum(pl);
+  if (lane == 0) {
+    s[0][wv] = mx;
+    s[1][wv] = sum;
+    s[2][wv] = pl;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < 256 / kWave; ++q) {
+      m = s[0][q] > m ? s[0][q] : m;
+      s1 += s[1][q];
+      s2 += s[2][q];
+    }
+    if (part_band) part_band[(c * a.panel_bands + a.bands[e].out_band) * nblk + band_slot] = s1;
+    if (part_stat) {
+      double* o = part_stat + (c * a.stat_slots + stat_slot0 + e) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
+    }
   }
 }
 
@@ -632,14 +753,40 @@ int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, i
 }
 
 template <typename T>
-int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st) {
+int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
+                       hipStream_t st) {
   dim3 g((unsigned)(ceil_div(n, 256) > 1024 ? 1024 : ceil_div(n, 256)), (unsigned)C);
-  k_time_reduce<T><<<g, 256, 0, st>>>(part, out, n, nchunk);
+  k_time_reduce<T><<<g, 256, 0, st>>>(part, out, n, nchunk, edge_time, wmax);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
-template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, hipStream_t);
-template int launch_time_reduce<double>(const double*, double*, int64_t, int64_t, int, hipStream_t);
+template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, hipStream_t);
+template int launch_time_reduce<double>(const double*, double*, int64_t, int64_t, int, const double*, int64_t,
+                                        hipStream_t);
+
+template <typename T>
+int launch_even_bins(const cplx<T>* x2, cplx<T>* x1, int64_t C, int64_t n, hipStream_t st) {
+  dim3 g((unsigned)ceil_div(n, 256), (unsigned)C);
+  k_even_bins<T><<<g, 256, 0, st>>>(x2, x1, n);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_even_bins<float>(const float2*, float2*, int64_t, int64_t, hipStream_t);
+
+template <typename T>
+int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band, int64_t nblk, int64_t band_slot,
+                double* part_stat, int64_t stat_slot, hipStream_t st) {
+  if (a.nedge <= 0) return QI_OK;
+  dim3 g((unsigned)ceil_div(2 * a.wmax, 256 / kWave), (unsigned)a.nedge, (unsigned)C);
+  k_edge_fix<T><<<g, 256, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  dim3 gr((unsigned)(a.nedge + ceil_div(2 * a.wmax, 256)), (unsigned)C);
+  k_edge_reduce<T><<<gr, 256, 0, st>>>(a, edge_time, part_band, nblk, band_slot, part_stat, stat_slot);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_edge<float>(const EdgeArgs<float>&, int64_t, float*, double*, int64_t, int64_t, double*, int64_t,
+                                hipStream_t);
 
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st) {
   k_band_support<<<nb, 256, 0, st>>>(F, L, thr2, out);

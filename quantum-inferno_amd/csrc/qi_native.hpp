@@ -15,6 +15,8 @@ struct BandDesc {
   int32_t gen_slot;  // general bands: slot of the intermediate buffer used by its launch group
   int32_t out_band;  // row of the panel this band writes
   int32_t bank_row;  // general Gabor bands: row of the full-spectrum bank
+  int32_t edge;      // circularly evaluated short-atom band: samples at each record end fixed by k_edge_fix
+  int32_t pad_;
   int64_t src_off;   // pruned Gabor bands: offset of H[k_lo] in the compact bank
   int64_t shift;     // Stockwell: shift index idx_j
   double coef;       // Stockwell: window coefficient (exp2(-(coef k)^2))
@@ -42,7 +44,8 @@ struct RowArgs {
   T* time_part;       // [C][chunk_total][n]
   double* part_band;  // [C][panel_bands][nblk]
   double* part_stat;  // [C][chunk_total][nblk][3]
-  int64_t nblk;       // N1 / G
+  int64_t nblk;       // partial slots per band (stride of part_band rows and of part_stat chunks)
+  int64_t stat_stride;  // part_stat entries per channel
   int32_t bands_per_chunk;
   T power_scale, eps;
   int32_t debug;  // QI_NATIVE_DEBUG bit mask (timing experiments only: 1 no stores, 2 no loads, 4 no FFT, 8 no reductions)
@@ -52,8 +55,31 @@ template <typename T>
 int launch_pass1(const RowArgs<T>& a, int kind, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_pass2(const RowArgs<T>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels, hipStream_t st);
+// one short-atom band of the styx bank evaluated circularly (see k_edge_fix)
+struct EdgeBand {
+  int32_t out_band, w;  // panel row; taps |u| <= w of the atom are above 2^-30 of its peak
+  double p_re, p_im, omega, amp;
+};
 template <typename T>
-int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, hipStream_t st);
+struct EdgeArgs {
+  const EdgeBand* bands;  // [nedge] device
+  int32_t nedge, panel_bands;
+  int64_t n, wmax, stat_slots;
+  const T* sig;       // [C][n]
+  cplx<T>* coef;      // panel
+  T* bits;            // optional
+  T* edge_p;          // [C][nedge][2][wmax] corrected powers
+  T power_scale, eps;
+};
+
+template <typename T>
+int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
+                       hipStream_t st);
+template <typename T>
+int launch_even_bins(const cplx<T>* x2, cplx<T>* x1, int64_t C, int64_t n, hipStream_t st);
+template <typename T>
+int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band, int64_t nblk, int64_t band_slot,
+                double* part_stat, int64_t stat_slot, hipStream_t st);
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st);
 template <typename T>
 int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
