@@ -34,17 +34,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, extra_flags=(), lib=None):
+    lib = lib or LIB
+    if not force and not extra_flags and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     tlib = torch_lib_dir()
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", ".dbg.o" if extra_flags else ".o"))
         cmd = [hipcc, "-c", "-fPIC", "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-I", os.path.join(ROOT, "include"),
-               "-I", CSRC, "-Wall", "-Wno-unused-function", os.path.join(CSRC, src), "-o", obj]
+               "-I", CSRC, "-Wall", "-Wno-unused-function", *extra_flags, os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -52,14 +53,18 @@ def build(force=False, verbose=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    link = ["g++", "-shared", "-o", LIB, *objs, f"-L{tlib}", "-lamdhip64", "-lhipfft", f"-Wl,-rpath,{tlib}",
+    link = ["g++", "-shared", "-o", lib, *objs, f"-L{tlib}", "-lamdhip64", "-lhipfft", f"-Wl,-rpath,{tlib}",
             "-Wl,--no-undefined", "-lpthread"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--stamps" in sys.argv:  # diagnostic library with in-kernel phase stamps (never the shipped one)
+        print(build(force=True, extra_flags=("-DQI_NATIVE_STAMPS", "-DQI_NATIVE_DEBUG"),
+                    lib=os.path.join(HERE, "libqi_tfr_stamps.so")))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -6,7 +6,7 @@ import os
 import torch  # first: its bundled HIP runtime must be the one libqi_tfr.so resolves against
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqi_tfr.so")
+LIB_PATH = os.environ.get("QI_TFR_LIB") or os.path.join(_HERE, "libqi_tfr.so")  # QI_TFR_LIB: diagnostic builds
 
 QI_F32, QI_F64 = 0, 1
 QI_BANK_STYX, QI_BANK_ATOMS, QI_TABLE_STX = 0, 1, 2

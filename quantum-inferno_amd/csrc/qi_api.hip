@@ -227,6 +227,7 @@ struct qi_plan {
   int native_short = 1;  // evaluate short-atom styx bands circularly at length n (0: everything at 2n)
   int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
   int native_debug = 0;
+  unsigned long long* stamps = nullptr;  // diagnostic builds: phase cycle counters of the last pass-2 launch
   int native_group = 0;        // wide bands per launch group (0: all in one group)
   int native_rows = 16;        // consecutive time residues (rows) per pass-2 workgroup: 8 or 16
 };
@@ -687,6 +688,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       a.inv_len = (T)(1.0 / (double)t.Lf);
       a.two_over_len = (float)(2.0 / (double)t.Lf);
       a.debug = p->native_debug;
+      a.stamps = p->stamps;
       a.neg_last_row = sb.kernel_kind == 0 ? 1 : 0;
       a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
       a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
@@ -834,6 +836,12 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
   if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
   if (const char* e = getenv("QI_NATIVE_GROUP")) p->native_group = atoi(e);
+#ifdef QI_NATIVE_STAMPS
+  if (getenv("QI_NATIVE_STAMPS")) {
+    if (hipMalloc((void**)&p->stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->stamps = nullptr;
+    if (p->stamps) (void)hipMemset(p->stamps, 0, 65536 * 8 * sizeof(unsigned long long));
+  }
+#endif
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -855,6 +863,26 @@ int qi_plan_destroy(qi_plan* p) {
   (void)hipDeviceSynchronize();
   p->fft.clear();
   p->prof.clear();
+#ifdef QI_NATIVE_STAMPS
+  if (p->stamps) {
+    std::vector<unsigned long long> h(65536 * 8);
+    if (hipMemcpy(h.data(), p->stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum[8] = {0};
+      long cnt = 0;
+      for (size_t w = 0; w < 65536; ++w) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; ++k) tot += h[w * 8 + k];
+        if (!tot) continue;
+        ++cnt;
+        for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+      }
+      fprintf(stderr, "[qi stamps] last pass-2 launch, %ld workgroups, mean cycles per workgroup: load %.0f | barrier %.0f | "
+              "step1 %.0f | barrier %.0f | exchange %.0f | step2 %.0f | epilogue %.0f | loop head %.0f\n", cnt,
+              sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt);
+    }
+    (void)hipFree(p->stamps);
+  }
+#endif
   for (auto& t : p->nat) t.release();
   if (p->d_edge) (void)hipFree(p->d_edge);
   for (int b = 0; b < 2; ++b)

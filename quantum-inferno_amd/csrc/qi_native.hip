@@ -104,7 +104,8 @@ struct Cfg {
   static constexpr int SR = NR + 1;       // row stride of the natural-order image A[g][k]
   static constexpr int SA = 32 * G_ + 1;  // a-stride of the exchange image E[a][...]
   static constexpr int BUF = (G_ * SR > 32 * SA) ? G_ * SR : 32 * SA;
-  static constexpr size_t LDS_BYTES = ((size_t)BUF + NR) * sizeof(cplx<T>) + 256;
+  static constexpr int TW1 = (kMaxPrunedTerms + 1) * G_;  // inner twiddles of the pruned loader
+  static constexpr size_t LDS_BYTES = ((size_t)BUF + NR + TW1) * sizeof(cplx<T>) + 256;
 };
 
 #ifdef QI_NATIVE_DEBUG
@@ -113,69 +114,116 @@ struct Cfg {
 #define QI_DBG(bit) false
 #endif
 
+// In-kernel phase stamps (diagnostic build only, -DQI_NATIVE_STAMPS): wave 0 of every workgroup sums the cycles it
+// spends in each phase of the band loop; never enabled in the shipped library.
+#ifdef QI_NATIVE_STAMPS
+#define QI_STAMP(k)                                                        \
+  do {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                    \
+    st_acc[k] += now_ - st_last;                                           \
+    st_last = now_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+  } while (0)
+#else
+#define QI_STAMP(k)
+#endif
+
 __device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
 __device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 
 // ---- loaders: fill A[g][k] (row stride SR) for the G rows of this workgroup ---------------------------------------
-// pruned: A[g][k mod 1024] = sum_k Y[k] W_Lf^(k (t1_0 + g))
+// pruned: A[g][s] = W_Lf^(s t1_g) * sum_m Y[s + 1024 (k1_min + m)] W_N1^((k1_min + m) t1_g),  t1_g = t1_0 + g.
+// The inner twiddles depend on (m, g) only: they are computed once per band into `tw1` (LDS, NTERM x G values)
+// and broadcast; the outer twiddle is one float64 recurrence over g per slot from exact-phase seeds.  Each thread
+// owns the slots tid and tid + TH/…; all global loads of a slot pair are issued before any arithmetic.
 template <typename T, class C, bool STX>
-__device__ __forceinline__ void load_pruned(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd,
+__device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowArgs<T>& a, const BandDesc& bd,
                                             const cplx<T>* __restrict__ X, uint32_t t1_0) {
-  constexpr int MAXM = kMaxPrunedTerms;  // support bins that can fall on one slot (k_len <= MAXM * 1024)
+  constexpr int MAXM = kMaxPrunedTerms + 1;  // distinct k1 = floor(k / 1024) a support of <= 8192 bins can touch
+  constexpr int SPT = C::NR / C::TH;         // slots per thread
   const int tid = threadIdx.x;
   const uint32_t mask = (uint32_t)a.Lf - 1u;  // Lf is a power of two: x mod Lf == x & mask, also for negative x
   const int32_t k_end = bd.k_lo + bd.k_len;
+  const int32_t k1_min = bd.k_lo >> 10;            // arithmetic shift = floor for negative k_lo
+  const int32_t nterm = ((k_end - 1) >> 10) - k1_min + 1;
   const cplx<T>* __restrict__ Hc = STX ? nullptr : a.Hc + bd.src_off;
+  // inner twiddles W_Lf^(1024 k1 t1_g)
+  if (tid < MAXM * C::G) {
+    const int m = tid / C::G, g = tid % C::G;
+    double wr, wi;
+    unit_root(((uint32_t)((k1_min + m) * 1024) * (t1_0 + (uint32_t)g)) & mask, a.two_over_len, &wr, &wi);
+    tw1[tid] = mk<T>((T)wr, (T)wi);
+  }
+  __syncthreads();
+  cplx<T> acc[SPT][C::G];
+  bool has[SPT];
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    has[q] = false;
+#pragma unroll
+    for (int g = 0; g < C::G; ++g) acc[q][g] = mk<T>(T(0), T(0));
+  }
 #pragma unroll 1
-  for (int slot = tid; slot < C::NR; slot += C::TH) {
-    const int32_t k0 = bd.k_lo + ((slot - bd.k_lo) & (C::NR - 1));
-    // issue every global load of this slot first so that their latencies overlap
-    cplx<T> xs[MAXM], hs[MAXM];
+  for (int m = 0; m < nterm; ++m) {
+    cplx<T> y[SPT];
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int32_t k = k0 + m * C::NR;
-      xs[m] = mk<T>(T(0), T(0));
-      hs[m] = mk<T>(T(1), T(0));
-      if (k < k_end) {
+    for (int q = 0; q < SPT; ++q) {
+      const int32_t k = tid + q * C::TH + 1024 * (k1_min + m);
+      y[q] = mk<T>(T(0), T(0));
+      if (k >= bd.k_lo && k < k_end) {
+        has[q] = true;
         if constexpr (STX) {
-          xs[m] = X[(uint32_t)(k + (int32_t)bd.shift) & mask];
-        } else {
-          xs[m] = X[k];
-          hs[m] = Hc[k - bd.k_lo];
-        }
-      }
-    }
-    cplx<T> acc[C::G];
-#pragma unroll
-    for (int g = 0; g < C::G; ++g) acc[g] = mk<T>(T(0), T(0));
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int32_t k = k0 + m * C::NR;
-      if (k < k_end) {
-        cplx<T> y;
-        if constexpr (STX) {
+          const cplx<T> x = X[(uint32_t)(k + (int32_t)bd.shift) & mask];
           const T e = (T)bd.coef * (T)k;
           const T w = exp2_t(-e * e) * a.inv_len;
-          y = mk<T>(xs[m].x * w, xs[m].y * w);
+          y[q] = mk<T>(x.x * w, x.y * w);
         } else {
-          y = cmul(xs[m], hs[m]);
-        }
-        double wr, wi, sr, si;
-        unit_root(((uint32_t)k * t1_0) & mask, a.two_over_len, &wr, &wi);
-        unit_root((uint32_t)k & mask, a.two_over_len, &sr, &si);
-#pragma unroll
-        for (int g = 0; g < C::G; ++g) {
-          const T cr = (T)wr, ci = (T)wi;
-          acc[g].x += y.x * cr - y.y * ci;
-          acc[g].y += y.x * ci + y.y * cr;
-          const double nr = wr * sr - wi * si;
-          wi = wr * si + wi * sr;
-          wr = nr;
+          y[q] = cmul(X[k], Hc[k - bd.k_lo]);
         }
       }
     }
+    bool any = false;
 #pragma unroll
-    for (int g = 0; g < C::G; ++g) A[g * C::SR + slot] = acc[g];
+    for (int q = 0; q < SPT; ++q) any = any || (y[q].x != T(0) || y[q].y != T(0));
+    if (any) {
+#pragma unroll
+      for (int g = 0; g < C::G; ++g) {
+        const cplx<T> w = tw1[m * C::G + g];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+          acc[q][g].x += y[q].x * w.x - y[q].y * w.y;
+          acc[q][g].y += y[q].x * w.y + y[q].y * w.x;
+        }
+      }
+    }
+  }
+  // outer twiddle W_Lf^(s t1_g) and store; slots outside the support only store zeros.  The twiddles do not depend
+  // on the band: t1 is made opaque so that they are recomputed where needed instead of being hoisted out of the band
+  // loop for every slot (64 registers that would spill).
+  __builtin_amdgcn_sched_barrier(0);
+  uint32_t t1v = t1_0;
+  asm volatile("" : "+v"(t1v));
+#pragma unroll
+  for (int q = 0; q < SPT; ++q) {
+    const uint32_t sl = (uint32_t)(tid + q * C::TH);
+    if (has[q]) {
+      double wr, wi, sr, si;
+      unit_root((sl * t1v) & mask, a.two_over_len, &wr, &wi);
+      unit_root(sl & mask, a.two_over_len, &sr, &si);
+#pragma unroll
+      for (int g = 0; g < C::G; ++g) {
+        const T cr = (T)wr, ci = (T)wi;
+        A[g * C::SR + sl] = mk<T>(acc[q][g].x * cr - acc[q][g].y * ci, acc[q][g].x * ci + acc[q][g].y * cr);
+        const double nr = wr * sr - wi * si;
+        wi = wr * si + wi * sr;
+        wr = nr;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < C::G; ++g) A[g * C::SR + sl] = mk<T>(T(0), T(0));
+    }
   }
 }
 
@@ -254,7 +302,11 @@ __device__ __forceinline__ void fill_step_twiddles(cplx<T>* tw) {
 // workgroup: two register radix-32 steps and one exchange through LDS.  The caller has synchronised after filling
 // buf; on return buf is free again and thread (g2, d2) holds out[d2 + 32 c] in u[brev(c, 5)].
 template <typename T, class C>
-__device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[32], bool skip) {
+__device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[32], bool skip
+#ifdef QI_NATIVE_STAMPS
+                                             , unsigned long long (&st_acc)[8], unsigned long long& st_last
+#endif
+) {
   const int tid = threadIdx.x;
   const int g1 = tid / 32, a1 = tid % 32;
   const int g2 = C::DFAST ? tid / 32 : tid % C::G;
@@ -269,7 +321,9 @@ __device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cp
     for (int d = 1; d < 32; ++d) v[brev(d, 5)] = cmul(v[brev(d, 5)], tw[d * 32 + a1]);
   }
   __builtin_amdgcn_sched_barrier(0);
+  QI_STAMP(2);
   __syncthreads();
+  QI_STAMP(3);
 #pragma unroll
   for (int d = 0; d < 32; ++d) buf[a1 * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[brev(d, 5)];
   __builtin_amdgcn_sched_barrier(0);
@@ -279,8 +333,10 @@ __device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cp
   for (int aa = 0; aa < 32; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  QI_STAMP(4);
   if (!skip) fft_reg<T, 32, 1>(u);
   __builtin_amdgcn_sched_barrier(0);
+  QI_STAMP(5);
 }
 
 // ---- pass 1 (wide bands only) ---------------------------------------------------------------------------------------
@@ -303,13 +359,21 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const cplx<T>* Xc = a.X + ch * a.Lf;
   const uint32_t mask = (uint32_t)a.Lf - 1u;
 
+#ifdef QI_NATIVE_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   cplx<T> u[NPH][32];
 #pragma unroll
   for (int ph = 0; ph < NPH; ++ph) {
     if (!QI_DBG(2)) load_full<T, C, STX, NPH>(buf, a, bd, Xc, row0, ph);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+#ifdef QI_NATIVE_STAMPS
+    rows_fft1024<T, C>(buf, tw, u[ph], QI_DBG(4), st_acc, st_last);
+#else
     rows_fft1024<T, C>(buf, tw, u[ph], QI_DBG(4));
+#endif
   }
   const uint32_t k2 = row0 + g2;
   // The linear kind's pass 2 works on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken
@@ -402,25 +466,36 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
   int par = 0;
 
+#ifdef QI_NATIVE_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   // list entries blockIdx.y, blockIdx.y + nchunk, ...: every chunk gets the same mix of narrow and wide bands
   for (int64_t jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
     const BandDesc bd = a.bands[jj];
     const int64_t j = bd.out_band;  // row of the panel this band writes
+    QI_STAMP(7);
     if (!QI_DBG(2)) {
       if (bd.mode == 0)
-        load_pruned<T, C, STX>(buf, a, bd, Xc, t1_first);
+        load_pruned<T, C, STX>(buf, tw + C::NR, a, bd, Xc, t1_first);
       else
         load_imd<T, C>(buf, a.imd + ((int64_t)ch * a.imd_slots + bd.gen_slot) * a.Lf, (uint32_t)a.N1, row0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    QI_STAMP(0);
     __syncthreads();
+    QI_STAMP(1);
     if (pending >= 0 && tid == 0) {
       double s = 0.0;
       for (int w = 0; w < C::TH / kWave; ++w) s += s_red[par ^ 1][w];
       a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + grp] = s;
     }
     cplx<T> u[32];
+#ifdef QI_NATIVE_STAMPS
+    rows_fft1024<T, C>(buf, tw, u, QI_DBG(4), st_acc, st_last);
+#else
     rows_fft1024<T, C>(buf, tw, u, QI_DBG(4));
+#endif
 
     const int64_t orow = ((int64_t)ch * a.panel_bands + j) * a.n;
     char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
@@ -459,7 +534,14 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       pending = j;
       par ^= 1;
     }
+    QI_STAMP(6);
   }
+#ifdef QI_NATIVE_STAMPS
+  if (a.stamps && tid == 0) {
+    unsigned long long* o = a.stamps + ((((int64_t)ch * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8);
+    for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+  }
+#endif
 
   __syncthreads();
   if (pending >= 0 && tid == 0) {

@@ -48,6 +48,7 @@ struct RowArgs {
   int64_t stat_stride;  // part_stat entries per channel
   int32_t bands_per_chunk;
   T power_scale, eps;
+  unsigned long long* stamps;  // diagnostic builds only (-DQI_NATIVE_STAMPS): [workgroup][8] phase cycles
   int32_t debug;  // QI_NATIVE_DEBUG bit mask (timing experiments only: 1 no stores, 2 no loads, 4 no FFT, 8 no reductions)
 };
 

@@ -10,6 +10,7 @@ PyTorch is used for device memory and streams only.
 """
 import collections
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -131,6 +132,8 @@ class TfrPlan:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.workspace_bytes = int(workspace_bytes) if workspace_bytes else 0
         self._handle = C.c_void_p()
+        if os.environ.get("QI_FORCE_HIPFFT"):  # testing aid: run everything on the hipFFT engine
+            engine = _lib.QI_ENGINE_HIPFFT
         desc = _lib.PlanDesc(
             n=self.n,
             dtype=_lib.QI_F64 if self.rdtype == torch.float64 else _lib.QI_F32,

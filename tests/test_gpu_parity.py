@@ -267,3 +267,62 @@ def test_batches_tiles_and_oracle_on_noise():
     # CUDA tensor in -> CUDA tensor out
     out = styx_stx.stx_complex_any_scale_pow2(order, xt[0], fs)[2]
     assert isinstance(out, torch.Tensor) and out.is_cuda and out.shape == ref_s[0].shape
+
+
+def test_native_engine_batches_match_single_records():
+    """Native engine (float32, n = 2^20 and 2^19): a 3-channel batch equals the three single-record results and the
+    hipFFT engine on the same input; also with a workspace that forces channel tiling."""
+    from quantum_inferno_amd import _lib
+
+    fs, order = 1000.0, 3
+    for n in (1 << 20, 1 << 19):
+        x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 3, np.float32) for c in range(3)])).cuda()
+        plan = _plan_with_all(n, fs, order, np.float32, channels=3)
+        ref = engine.TfrPlan(n, np.float32, None, engine.TfrPlan.workspace_for(n, len(plan.freq[0]), np.float32, 1),
+                             _lib.QI_ENGINE_HIPFFT)
+        ref.set_styx_bank(order, fs)
+        ref.set_stx_bands(order, fs)
+        for name in ("cwt", "stx"):
+            batch = getattr(plan, name)(x, coef=True, bits=(n == 1 << 19), reductions=True)
+            for c in range(3):
+                one = getattr(plan, name)(x[c : c + 1], coef=True, reductions=True)
+                assert torch.equal(one.coef[0], batch.coef[c]), (name, n, c)
+                assert torch.equal(one.power_band[0], batch.power_band[c])
+                # the band-chunking (hence the summation order over bands) depends on the channel count
+                assert torch.allclose(one.power_time[0], batch.power_time[c], rtol=1e-5, atol=1e-7 * float(one.power_time.max()))
+                assert torch.allclose(one.stats[0], batch.stats[c], rtol=1e-5)
+            gold = getattr(ref, name)(x[1:2], coef=True, bits=(n == 1 << 19), reductions=True)
+            scale = float(gold.coef.abs().max())
+            assert float((gold.coef[0] - batch.coef[1]).abs().max()) / scale <= 2e-5, (name, n)
+            assert torch.allclose(gold.power_band[0], batch.power_band[1], rtol=1e-4)
+            assert torch.allclose(gold.power_time[0], batch.power_time[1], rtol=1e-3, atol=1e-6 * float(gold.power_time.max()))
+            assert torch.allclose(gold.stats[0, :3], batch.stats[1, :3], rtol=1e-4)
+            if batch.bits is not None:
+                big = gold.coef[0].abs() >= 1e-2 * scale
+                assert float((gold.bits[0] - batch.bits[1]).abs()[big].max()) <= 1e-3
+            del batch, gold
+        ref.close()
+        plan.close()
+    # channel tiling: workspace for one record only
+    n = 1 << 20
+    x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 2, np.float32) for c in range(2)])).cuda()
+    big = _plan_with_all(n, fs, order, np.float32, channels=2)
+    small = _plan_with_all(n, fs, order, np.float32, channels=1)
+    for name in ("cwt", "stx"):
+        a, b = getattr(big, name)(x, coef=True, reductions=True), getattr(small, name)(x, coef=True, reductions=True)
+        assert torch.equal(a.coef, b.coef) and torch.allclose(a.stats, b.stats, rtol=1e-5)
+        assert torch.allclose(a.power_time, b.power_time, rtol=1e-5, atol=1e-7 * float(a.power_time.max()))
+    big.close()
+    small.close()
+    # cwt_atoms on the native engine (circular bank, roll by n/2) against the hipFFT engine
+    sig = x[0].cpu().numpy()
+    c_nat = cwt_atoms.cwt_chirp_from_sig(sig, fs, 3)[0]
+    import os
+    engine.clear_plans()
+    os.environ["QI_FORCE_HIPFFT"] = "1"
+    try:
+        c_ref = cwt_atoms.cwt_chirp_from_sig(sig, fs, 3)[0]
+    finally:
+        del os.environ["QI_FORCE_HIPFFT"]
+        engine.clear_plans()
+    assert relmax(c_nat, c_ref) <= 2e-5
