@@ -227,6 +227,8 @@ struct qi_plan {
   int native_short = 1;  // evaluate short-atom styx bands circularly at length n (0: everything at 2n)
   int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
   int native_debug = 0;
+  int native_fwd = 1;          // forward transform of the records on the native kernels (0: hipFFT)
+  int native_wgs = 256;        // workgroups a pass-2 launch should have at least (band chunks are sized for it)
   unsigned long long* stamps = nullptr;  // diagnostic builds: phase cycle counters of the last pass-2 launch
   int native_group = 0;        // wide bands per launch group (0: all in one group)
   int native_rows = 16;        // consecutive time residues (rows) per pass-2 workgroup: 8 or 16
@@ -614,13 +616,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     if ((int64_t)sb.t->imd_slots * sb.t->Lf > imd_elems) imd_elems = (int64_t)sb.t->imd_slots * sb.t->Lf;
     for (const auto& grp : sb.t->groups) {
       // chunks (workgroups along the band list): enough workgroups to fill the chip
-      int nc = (int)ceil_div(512, sb.nblk * C);
+      int nc = (int)ceil_div(p->native_wgs, sb.nblk * C);
       if (nc < 1) nc = 1;
       if (nc > grp.count) nc = grp.count;
       sb.nchunk.push_back(nc);
       chunk_total += nc;
     }
   }
+  if (imd_elems < Lf0) imd_elems = Lf0;  // the forward transform of the records stages through one slot
   const int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
   const int64_t stat_slots = (int64_t)chunk_total * nbk + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
@@ -664,8 +667,22 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
     p->prof.begin(st);
-    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf0, st));
-    QI_TRY(fft_c2c<T>(p->fft, X, Lf0, ct, HIPFFT_FORWARD, st));
+    if (p->native_fwd) {
+      native::RowArgs<T> f{};
+      f.Lf = Lf0;
+      f.n = n;
+      f.N1 = Lf0 / native::kN2;
+      f.N2 = native::kN2;
+      f.imd_slots = 1;
+      f.imd = imd;
+      f.sig = sig + c0 * n;
+      f.two_over_len = (float)(2.0 / (double)Lf0);
+      f.debug = 0;
+      QI_TRY(native::launch_forward<T>(f, X, ct, st));
+    } else {
+      QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf0, st));
+      QI_TRY(fft_c2c<T>(p->fft, X, Lf0, ct, HIPFFT_FORWARD, st));
+    }
     if (shorts) QI_TRY(native::launch_even_bins<T>(X, Xn, ct, n, st));
     if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.end(QI_STAGE_FORWARD, st);
@@ -836,6 +853,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
   if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
   if (const char* e = getenv("QI_NATIVE_GROUP")) p->native_group = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_WGS")) p->native_wgs = atoi(e) > 0 ? atoi(e) : 256;
+  if (const char* e = getenv("QI_NATIVE_FWD")) p->native_fwd = atoi(e);
 #ifdef QI_NATIVE_STAMPS
   if (getenv("QI_NATIVE_STAMPS")) {
     if (hipMalloc((void**)&p->stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->stamps = nullptr;

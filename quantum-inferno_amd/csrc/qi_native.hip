@@ -245,42 +245,61 @@ __device__ __forceinline__ void load_imd(cplx<T>* A, const cplx<T>* __restrict__
   }
 }
 
-// general pass 1: A[r][m] = Y[k2_0 + r + N2 (NPH m + ph)]   (phase ph of NPH interleaved sub-sequences of k1)
-template <typename T, class C, bool STX, int NPH>
+// pass-1 operand Y[k] of one band: spectrum x stored bank row (SRC 0), shifted spectrum x Gaussian (SRC 1), or the
+// real record itself, zero beyond n (SRC 2: forward transform of the records)
+template <typename T, int SRC>
+__device__ __forceinline__ cplx<T> pass1_operand(const RowArgs<T>& a, const BandDesc& bd, const cplx<T>* __restrict__ X,
+                                                 const cplx<T>* __restrict__ H, const T* __restrict__ sig, uint32_t k,
+                                                 uint32_t mask) {
+  if constexpr (SRC == 1) {
+    const cplx<T> x = X[(k + (uint32_t)bd.shift) & mask];
+    const int32_t ks = (k <= (mask >> 1)) ? (int32_t)k : (int32_t)k - (int32_t)(mask + 1u);
+    const T e = (T)bd.coef * (T)ks;
+    const T w = exp2_t(-e * e) * a.inv_len;
+    return mk<T>(x.x * w, x.y * w);
+  } else if constexpr (SRC == 0) {
+    return cmul(X[k], H[k]);
+  } else {
+    return mk<T>(k < (uint32_t)a.n ? sig[k] : T(0), T(0));
+  }
+}
+
+// pass 1 loader: rows are the G consecutive k2 = k2_0 + r, columns the 1024 inputs of phase `ph` of the transform
+// over k1.  N1 = 1024: the column is Y[k2 + 1024 m].  N1 = 2048 (decimation in frequency): phase 0 transforms
+// Y[m] + Y[m + 1024] (outputs t1 = 2 c), phase 1 (Y[m] - Y[m + 1024]) W_2048^m (outputs t1 = 2 c + 1); both phases
+// read the operands again instead of holding a second result set in registers.
+template <typename T, class C, int SRC, int NPH>
 __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const BandDesc& bd,
-                                          const cplx<T>* __restrict__ X, uint32_t k2_0, int ph) {
+                                          const cplx<T>* __restrict__ X, const T* __restrict__ sig, uint32_t k2_0,
+                                          int ph) {
   const int tid = threadIdx.x;
   const int r = tid % C::G;
-  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = 8;
+  constexpr int STEP = C::TH / C::G, ITERS = C::NR / STEP, BATCH = NPH == 1 ? 8 : 4;
   static_assert(ITERS % BATCH == 0, "batch");
   const uint32_t mask = (uint32_t)a.Lf - 1u;
-  const cplx<T>* __restrict__ H = STX ? nullptr : a.Hfull + (int64_t)bd.bank_row * a.Lf;
+  const cplx<T>* __restrict__ H = SRC == 0 ? a.Hfull + (int64_t)bd.bank_row * a.Lf : nullptr;
 #pragma unroll 1
   for (int it = 0; it < ITERS; it += BATCH) {
-    cplx<T> xs[BATCH], hs[BATCH];
+    cplx<T> ys[BATCH][NPH];
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const uint32_t m = (uint32_t)(tid / C::G + (it + u) * STEP);
-      const uint32_t k = k2_0 + r + (uint32_t)kN2 * (NPH * m + ph);
-      if constexpr (STX) {
-        xs[u] = X[(k + (uint32_t)bd.shift) & mask];
-      } else {
-        xs[u] = X[k];
-        hs[u] = H[k];
-      }
+#pragma unroll
+      for (int h = 0; h < NPH; ++h)
+        ys[u][h] = pass1_operand<T, SRC>(a, bd, X, H, sig, k2_0 + r + (uint32_t)kN2 * (m + 1024u * h), mask);
     }
 #pragma unroll
     for (int u = 0; u < BATCH; ++u) {
       const uint32_t m = (uint32_t)(tid / C::G + (it + u) * STEP);
-      cplx<T> y;
-      if constexpr (STX) {
-        const uint32_t k = k2_0 + r + (uint32_t)kN2 * (NPH * m + ph);
-        const int32_t ks = (k <= (mask >> 1)) ? (int32_t)k : (int32_t)k - (int32_t)(mask + 1u);
-        const T e = (T)bd.coef * (T)ks;
-        const T w = exp2_t(-e * e) * a.inv_len;
-        y = mk<T>(xs[u].x * w, xs[u].y * w);
-      } else {
-        y = cmul(xs[u], hs[u]);
+      cplx<T> y = ys[u][0];
+      if constexpr (NPH == 2) {
+        if (ph == 0) {
+          y = mk<T>(ys[u][0].x + ys[u][1].x, ys[u][0].y + ys[u][1].y);
+        } else {
+          float sn, cs;
+          sincospif((float)m * (1.0f / 1024.0f), &sn, &cs);  // W_2048^m
+          y = cmul(mk<T>(ys[u][0].x - ys[u][1].x, ys[u][0].y - ys[u][1].y), mk<T>((T)cs, (T)sn));
+        }
       }
       A[r * C::SR + m] = y;
     }
@@ -339,12 +358,10 @@ __device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cp
   QI_STAMP(5);
 }
 
-// ---- pass 1 (wide bands only) ---------------------------------------------------------------------------------------
+// ---- pass 1 (wide bands, and the forward transform of the records) -------------------------------------------------
 // Rows are G consecutive k2; the transform runs over k1 (N1 = 1024 NPH points) and the result, multiplied by the
-// pass twiddle W_Lf^(k2 t1), is written to imd[k2][t1] in rows of N1 contiguous values.  N1 = 2048 is evaluated as
-// two 1024-point transforms of the even and odd k1 (each reading every 128-byte line of the operands exactly once)
-// combined by one radix-2 step in registers.
-template <typename T, class C, bool STX, int NPH>
+// pass twiddle W_Lf^(k2 t1), is written to imd[k2][t1] in rows of N1 contiguous values.
+template <typename T, class C, int SRC, int NPH>
 __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
@@ -354,77 +371,81 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const uint32_t row0 = blockIdx.x * C::G;
   const int g2 = tid / 32, d2 = tid % 32;  // DFAST mapping
   fill_step_twiddles<T, C>(tw);
-  const int32_t j = a.gen_list[blockIdx.y];
-  const BandDesc bd = a.bands[j];
-  const cplx<T>* Xc = a.X + ch * a.Lf;
+  BandDesc bd{};
+  if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y]];
+  const cplx<T>* Xc = SRC == 2 ? nullptr : a.X + ch * a.Lf;
+  const T* sigc = SRC == 2 ? a.sig + ch * a.n : nullptr;
   const uint32_t mask = (uint32_t)a.Lf - 1u;
-
-#ifdef QI_NATIVE_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long st_last = __builtin_amdgcn_s_memtime();
-#endif
-  cplx<T> u[NPH][32];
-#pragma unroll
-  for (int ph = 0; ph < NPH; ++ph) {
-    if (!QI_DBG(2)) load_full<T, C, STX, NPH>(buf, a, bd, Xc, row0, ph);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-#ifdef QI_NATIVE_STAMPS
-    rows_fft1024<T, C>(buf, tw, u[ph], QI_DBG(4), st_acc, st_last);
-#else
-    rows_fft1024<T, C>(buf, tw, u[ph], QI_DBG(4));
-#endif
-  }
   const uint32_t k2 = row0 + g2;
   // The linear kind's pass 2 works on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken
   // at -1): columns are stored at r = (t1 + 1) mod N1 so that pass 2 reads aligned runs of G columns.
   cplx<T>* __restrict__ dst = a.imd + (((int64_t)ch * a.imd_slots + bd.gen_slot) * a.N2 + k2) * a.N1;
   const uint32_t roll = a.neg_last_row ? 1u : 0u, cmask = (uint32_t)a.N1 - 1u;
-  // pass twiddle W_Lf^(k2 t1) along t1 = d2 + 32 c by a float64 recurrence from single-precision seeds
-  double wr, wi, sr, si;
-  unit_root((k2 * (uint32_t)d2) & mask, a.two_over_len, &wr, &wi);
-  unit_root((k2 * 32u) & mask, a.two_over_len, &sr, &si);
-  if constexpr (NPH == 1) {
+#ifdef QI_NATIVE_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+  for (int ph = 0; ph < NPH; ++ph) {
+    if (!QI_DBG(2)) load_full<T, C, SRC, NPH>(buf, a, bd, Xc, sigc, row0, ph);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    cplx<T> u[32];
+#ifdef QI_NATIVE_STAMPS
+    rows_fft1024<T, C>(buf, tw, u, QI_DBG(4), st_acc, st_last);
+#else
+    rows_fft1024<T, C>(buf, tw, u, QI_DBG(4));
+#endif
+    // pass twiddle W_Lf^(k2 t1) along t1 = NPH (d2 + 32 c) + ph by a float64 recurrence from single-precision seeds
+    double wr, wi, sr, si;
+    unit_root((k2 * (uint32_t)(NPH * d2 + ph)) & mask, a.two_over_len, &wr, &wi);
+    unit_root((k2 * (uint32_t)(32 * NPH)) & mask, a.two_over_len, &sr, &si);
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-      const cplx<T> z = u[0][brev(c, 5)];
-      if (c == 31 && a.neg_last_row && d2 == 31)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
+      const cplx<T> z = u[brev(c, 5)];
+      const uint32_t t1 = (uint32_t)(NPH * (d2 + 32 * c)) + (uint32_t)ph;
+      if (c == 31 && a.neg_last_row && t1 == cmask)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
         unit_root((0u - k2) & mask, a.two_over_len, &wr, &wi);
       const T cr = (T)wr, ci = (T)wi;
-      if (!QI_DBG(1)) dst[(d2 + 32u * c + roll) & cmask] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
+      if (!QI_DBG(1)) dst[(t1 + roll) & cmask] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
       const double nr = wr * sr - wi * si;
       wi = wr * si + wi * sr;
       wr = nr;
     }
-  } else {
-    // X[t] = E[t] + W_2048^t O[t], X[t + 1024] = E[t] - W_2048^t O[t], t = d2 + 32 c; W_2048^t = W_2048^d2 W_64^c
-    float s2, c2;
-    sincospif((float)d2 * (1.0f / 1024.0f), &s2, &c2);
-    double hr, hi;  // W_Lf^(1024 k2): ratio between the pass twiddles of t + 1024 and t
-    unit_root((k2 * 1024u) & mask, a.two_over_len, &hr, &hi);
-    const T hrf = (T)hr, hif = (T)hi;
-    mul_w64_powers<T>(u[1], std::make_integer_sequence<int, 32>{});
+  }
+}
+
+// ---- forward transform of the records, second pass -----------------------------------------------------------------
+// X = conj(IDFT(x)) for a real record x: pass 1 (SRC 2) ran the inverse machinery on the record; here rows are G
+// consecutive frequency residues f1, the transform runs over t2 and X[f1 + N1 f2] = conj(result) is written in
+// natural order (runs of G consecutive bins).
+template <typename T, class C>
+__global__ void __launch_bounds__(C::TH) k_fwd2(RowArgs<T> a, cplx<T>* __restrict__ Xout) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* tw = buf + C::BUF;
+  const int tid = threadIdx.x;
+  const int64_t ch = blockIdx.z;
+  const uint32_t row0 = blockIdx.x * C::G;
+  const int g2 = tid % C::G, d2 = tid / C::G;
+  fill_step_twiddles<T, C>(tw);
+  load_imd<T, C>(buf, a.imd + (int64_t)ch * a.imd_slots * a.Lf, (uint32_t)a.N1, row0);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  cplx<T> u[32];
+#ifdef QI_NATIVE_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = 0;
+  rows_fft1024<T, C>(buf, tw, u, false, st_acc, st_last);
+#else
+  rows_fft1024<T, C>(buf, tw, u, false);
+#endif
+  cplx<T>* __restrict__ dst = Xout + ch * a.Lf + row0 + g2 + (uint32_t)a.N1 * d2;
+  const uint32_t tstep = 32u * (uint32_t)a.N1;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const cplx<T> e = u[0][brev(c, 5)];
-      const cplx<T> o = cmul(u[1][brev(c, 5)], mk<T>((T)c2, (T)s2));
-      const cplx<T> lo = mk<T>(e.x + o.x, e.y + o.y), hi2 = mk<T>(e.x - o.x, e.y - o.y);
-      const T cr = (T)wr, ci = (T)wi;
-      T ur = cr * hrf - ci * hif, ui = cr * hif + ci * hrf;  // twiddle of t + 1024
-      if (c == 31 && a.neg_last_row && d2 == 31) {
-        double nr2, ni2;
-        unit_root((0u - k2) & mask, a.two_over_len, &nr2, &ni2);
-        ur = (T)nr2;
-        ui = (T)ni2;
-      }
-      if (!QI_DBG(1)) {
-        dst[(d2 + 32u * c + roll) & cmask] = mk<T>(lo.x * cr - lo.y * ci, lo.x * ci + lo.y * cr);
-        dst[(d2 + 32u * c + 1024u + roll) & cmask] = mk<T>(hi2.x * ur - hi2.y * ui, hi2.x * ui + hi2.y * ur);
-      }
-      const double nr = wr * sr - wi * si;
-      wi = wr * si + wi * sr;
-      wr = nr;
-    }
+  for (int c = 0; c < 32; ++c) {
+    const cplx<T> z = u[brev(c, 5)];
+    dst[(size_t)c * tstep] = mk<T>(z.x, -z.y);
   }
 }
 
@@ -791,10 +812,10 @@ static int launch_lds(Kern kern, bool* configured, size_t lds, const RowArgs<T>&
   return QI_OK;
 }
 
-template <typename T, class C, bool STX, int NPH>
+template <typename T, class C, int SRC, int NPH>
 static int launch_p1(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
   static bool configured = false;
-  return launch_lds(k_pass1<T, C, STX, NPH>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
+  return launch_lds(k_pass1<T, C, SRC, NPH>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
 }
 template <typename T, class C, int KIND>
 static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
@@ -808,10 +829,37 @@ int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, h
   using C = Cfg<float, 16, true>;
   dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
   const bool stx = kind == 2;
-  if (a.N1 == 1024) return stx ? launch_p1<float, C, true, 1>(a, grid, st) : launch_p1<float, C, false, 1>(a, grid, st);
-  if (a.N1 == 2048) return stx ? launch_p1<float, C, true, 2>(a, grid, st) : launch_p1<float, C, false, 2>(a, grid, st);
+  if (a.N1 == 1024) return stx ? launch_p1<float, C, 1, 1>(a, grid, st) : launch_p1<float, C, 0, 1>(a, grid, st);
+  if (a.N1 == 2048) return stx ? launch_p1<float, C, 1, 2>(a, grid, st) : launch_p1<float, C, 0, 2>(a, grid, st);
   set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
   return QI_ERR_UNSUPPORTED;
+}
+
+// forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
+template <>
+int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
+  using C1 = Cfg<float, 16, true>;
+  using C2 = Cfg<float, 16, false>;
+  dim3 g1((unsigned)(a.N2 / C1::G), 1, (unsigned)n_channels);
+  if (a.N1 == 1024)
+    QI_TRY((launch_p1<float, C1, 2, 1>(a, g1, st)));
+  else if (a.N1 == 2048)
+    QI_TRY((launch_p1<float, C1, 2, 2>(a, g1, st)));
+  else {
+    set_error("native forward transform supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
+    return QI_ERR_UNSUPPORTED;
+  }
+  static bool configured = false;
+  auto kern = k_fwd2<float, C2>;
+  if (!configured) {
+    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)C2::LDS_BYTES));
+    configured = true;
+  }
+  dim3 g2((unsigned)(a.N1 / C2::G), 1, (unsigned)n_channels);
+  kern<<<g2, C2::TH, C2::LDS_BYTES, st>>>(a, Xout);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
 }
 
 template <class C>

@@ -31,6 +31,7 @@ struct RowArgs {
   const int32_t* gen_list;  // [ngen_launch] indices into `bands` of its general bands (pass 1 launch order)
   int32_t ngen_launch, imd_slots;
   int32_t chunk_base, chunk_total;  // this launch owns chunks [chunk_base, chunk_base + gridDim.y) of chunk_total
+  const T* sig;          // [C][n] records (forward transform only)
   const cplx<T>* X;      // [C][Lf] spectra of the records
   const cplx<T>* Hc;     // compact bank of the pruned Gabor bands
   const cplx<T>* Hfull;  // [ngen][Lf] full spectra of the general Gabor bands
@@ -54,6 +55,8 @@ struct RowArgs {
 
 template <typename T>
 int launch_pass1(const RowArgs<T>& a, int kind, int64_t n_channels, hipStream_t st);
+template <typename T>
+int launch_forward(const RowArgs<T>& a, cplx<T>* Xout, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_pass2(const RowArgs<T>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels, hipStream_t st);
 // one short-atom band of the styx bank evaluated circularly (see k_edge_fix)
