@@ -6,7 +6,7 @@ namespace qi {
 namespace native {
 
 constexpr int kN2 = 1024;  // points of the in-LDS row transform of pass 2
-constexpr int kMaxPrunedTerms = 8;  // widest pruned support = kMaxPrunedTerms * kN2 spectrum bins
+constexpr int kMaxPrunedTerms = 16;  // widest pruned support = kMaxPrunedTerms * kN2 spectrum bins
 
 struct BandDesc {
   int32_t mode;      // 0: pruned (spectrum support short enough for the one-pass loader), 1: general
