@@ -152,13 +152,15 @@ def main():
         value = points_step * args.steps / dt / 1e6
         length = 2 * n
         alg_cwt, alg_stx = algorithmic_bytes(n_ch, n_b, n, length, real_bytes)
-        # dominant kernel = the stage with the largest summed device time on this rank
+        # dominant kernel = the stage with the largest summed device time on this rank (native engine: pass 2, the
+        # fused inverse-FFT row pass + epilogue; hipFFT engine: the batched inverse transform)
         name, (ms, launches) = max(stage.items(), key=lambda kv: kv[1][0])
         per_launch_ms = ms / max(launches, 1)
-        # every launch of that stage produces the coefficients of one (transform, tile): both transforms
-        # run it equally often, so one launch moves on average half the step's algorithmic bytes per tile
         launches_per_step = max(launches / args.steps, 1)
-        alg_per_launch = (alg_cwt + alg_stx) / launches_per_step
+        # algorithmic bytes of that kernel: it produces the complex coefficients, written once (SURVEY s8d:
+        # C*B*n*s_c), plus the per-time / per-band marginals; one launch handles points_step / launches_per_step points
+        alg_kernel_step = 2 * n_ch * n_b * n * 2 * real_bytes + 2 * n_ch * (n_b + n) * real_bytes
+        alg_per_launch = alg_kernel_step / launches_per_step
         achieved = alg_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")

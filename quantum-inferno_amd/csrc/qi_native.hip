@@ -659,19 +659,49 @@ __global__ void __launch_bounds__(256) k_edge_fix(EdgeArgs<T> a) {
   const int64_t t = side ? a.n - 1 - tloc : tloc;       // output sample
   const T* __restrict__ sig = a.sig + c * a.n;
   T sr = T(0), si = T(0);
-  for (int64_t i = lane; i < cnt; i += kWave) {
-    // head: m = n - W + t + i, u = m - t - n = i - W;  tail: m = i, u = m - t + n = i + 1 + tloc
-    const int64_t m = side ? i : a.n - eb.w + t + i;
-    const double x = (side ? (double)(i + 1 + tloc) : (double)(i - eb.w)) + 0.5;
-    const double ph = eb.omega * x - eb.p_im * x * x;
-    const double turns = ph * 0.15915494309189535;  // / 2 pi
-    const float frac = (float)(turns - rint(turns));
-    float sn, cs;
-    sincospif(2.0f * frac, &sn, &cs);
-    const float env = (float)eb.amp * expf(-(float)(eb.p_re * x * x));
-    const T v = sig[m] * (T)env;
-    sr += v * (T)cs;   // sig * conj(psi): conj(e^{i ph}) = cos - i sin
-    si -= v * (T)sn;
+  // head: m = n - W + t + i, u = m - t - n = i - W;  tail: m = i, u = m - t + n = i + 1 + tloc;  x = u + 1/2
+  const int64_t m0 = side ? 0 : a.n - eb.w + t;
+  const double x0 = (side ? (double)(1 + tloc) : (double)(-eb.w)) + 0.5;
+  const int64_t chunk = (cnt + kWave - 1) / kWave;
+  if (eb.p_im == 0.0 && chunk >= 4) {
+    // each lane takes `chunk` consecutive taps: phasor and Gaussian envelope by recurrences from exact seeds,
+    // conj(psi(x + 1)) = conj(psi(x)) e^{-i omega} e^{-p (2 x + 1)}
+    const int64_t i0 = (int64_t)lane * chunk;
+    const int64_t i1 = i0 + chunk < cnt ? i0 + chunk : cnt;
+    if (i0 < i1) {
+      const double x = x0 + (double)i0;
+      const double turns = eb.omega * x * 0.15915494309189535;
+      float sn, cs, sw, cw;
+      sincospif(2.0f * (float)(turns - rint(turns)), &sn, &cs);
+      const double tw_ = eb.omega * 0.15915494309189535;
+      sincospif(2.0f * (float)(tw_ - rint(tw_)), &sw, &cw);
+      float env = (float)eb.amp * expf(-(float)(eb.p_re * x * x));
+      float ratio = expf(-(float)(eb.p_re * (2.0 * x + 1.0)));
+      const float ratio2 = expf(-(float)(2.0 * eb.p_re));
+      float pr = cs, pi = -sn;  // conj phasor
+      for (int64_t i = i0; i < i1; ++i) {
+        const T v = sig[m0 + i] * (T)env;
+        sr += v * (T)pr;
+        si += v * (T)pi;
+        const float nr = pr * cw + pi * sw;  // times e^{-i omega}
+        pi = pi * cw - pr * sw;
+        pr = nr;
+        env *= ratio;
+        ratio *= ratio2;
+      }
+    }
+  } else {
+    for (int64_t i = lane; i < cnt; i += kWave) {
+      const double x = x0 + (double)i;
+      const double ph = eb.omega * x - eb.p_im * x * x;
+      const double turns = ph * 0.15915494309189535;  // / 2 pi
+      float sn, cs;
+      sincospif(2.0f * (float)(turns - rint(turns)), &sn, &cs);
+      const float env = (float)eb.amp * expf(-(float)(eb.p_re * x * x));
+      const T v = sig[m0 + i] * (T)env;
+      sr += v * (T)cs;  // sig * conj(psi): conj(e^{i ph}) = cos - i sin
+      si -= v * (T)sn;
+    }
   }
   sr = wave_sum(sr);
   si = wave_sum(si);
