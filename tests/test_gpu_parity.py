@@ -326,3 +326,28 @@ def test_native_engine_batches_match_single_records():
         del os.environ["QI_FORCE_HIPFFT"]
         engine.clear_plans()
     assert relmax(c_nat, c_ref) <= 2e-5
+
+
+def test_streaming_chunks_float64():
+    """Config-5 shape in miniature: a long float64 record as overlapped chunks; every chunk's reduced product equals
+    the transform of that chunk alone, and a run restarted at a chunk boundary reproduces the rest."""
+    from quantum_inferno_amd import stream
+
+    rng = np.random.default_rng(11)
+    n, hop, fs, order = 4096, 2048, 800.0, 12
+    x = rng.standard_normal((2, 3 * n + 777))
+    plan = _plan_with_all(n, fs, order, np.float64, channels=2)
+    seen = {}
+    for i, start, res in stream.stream_reduced(plan, x, hop, "cwt"):
+        seen[i] = (start, res.power_band.clone(), res.entropy_bits.clone())
+    assert len(seen) == len(stream.chunk_starts(x.shape[1], n, hop))
+    for i, (start, band, ent) in seen.items():
+        ref = np.stack([orc.cwt_fft(order, x[c, start : start + n], fs)[2] for c in range(2)])
+        p = np.abs(ref) ** 2
+        assert np.allclose(band.cpu().numpy(), p.sum(axis=2), rtol=1e-10)
+        assert np.allclose(ent.cpu().numpy(), [np.sum(orc.shannon_from_power(pc).shannon_bits) for pc in p], rtol=1e-10)
+    resumed = {i: r.power_band.clone() for i, _, r in stream.stream_reduced(plan, x, hop, "cwt", first_chunk=3)}
+    assert sorted(resumed) == [k for k in sorted(seen) if k >= 3]
+    for i, band in resumed.items():
+        assert torch.equal(band, seen[i][1])
+    plan.close()

@@ -108,3 +108,23 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.lower(), f"{fn} mentions the oracle"
+
+
+def test_stream_chunking_cursor():
+    from quantum_inferno_amd import stream
+
+    # BASELINE config 5: 24 h at 800 Hz in chunks of 2^20 with a hop of 2^19
+    starts = stream.chunk_starts(69_120_000, 1 << 20, 1 << 19)
+    assert len(starts) == 131 and starts[0] == 0 and starts[1] == 1 << 19
+    assert starts[-1] + (1 << 20) == 69_120_000 and np.all(np.diff(starts) > 0)
+    assert np.all(np.diff(starts)[:-1] == 1 << 19)
+    covered = np.zeros(69_120_000 // 4096, dtype=bool)  # 69 120 000 = 16 875 * 4096
+    for s0 in starts:
+        covered[s0 // 4096 : (s0 + (1 << 20) + 4095) // 4096] = True
+    assert covered.all()
+    assert np.array_equal(stream.chunk_starts(4096, 1024, 1024), [0, 1024, 2048, 3072])
+    with pytest.raises(ValueError):
+        stream.chunk_starts(1000, 1024, 512)
+    x = np.arange(2 * 5000, dtype=np.float64).reshape(2, 5000)
+    got = [(i, s0, v.shape) for i, s0, v in stream.iter_chunks(x, 2048, 1024, first_chunk=1)]
+    assert got == [(1, 1024, (2, 2048)), (2, 2048, (2, 2048)), (3, 2952, (2, 2048))]
