@@ -138,6 +138,25 @@ def gen_small():
     save("small_n1024.npz", **d)
 
 
+def gen_stx_general():
+    """styx_stx.tfr_stx_fft on its working subset (n_fft_in = len(sig), a power of two)."""
+    d = {}
+    n, fs = 1024, 1000.0
+    sig = synth_chirp(n, fs, dtype=np.float64)
+    d["sig"] = sig
+    cases = {
+        "lin": dict(frequency_min=20.0, frequency_max=400.0, frequency_step=20.0),
+        "geo": dict(scale_order_input=3.0, frequency_min=10.0, frequency_max=450.0, is_geometric=True),
+        "inferno": dict(scale_order_input=3.0, frequency_min=8.0, frequency_max=400.0, is_geometric=True, is_inferno=True),
+        "qpr": dict(frequency_min=25.0, frequency_max=300.0, frequency_step=25.0, factor_q=0.5, power_p=1.0, power_r=0.75),
+    }
+    for name, kw in cases.items():
+        tfr, psd, f, f_fft, win = quiet(styx_stx.tfr_stx_fft, sig, 1 / fs, n_fft_in=n, **kw)
+        d[f"{name}_tfr"], d[f"{name}_f"], d[f"{name}_ffft"] = tfr, f, f_fft
+        d[f"{name}_psd_row0"], d[f"{name}_win_rows"] = psd[0], win[[0, len(f) - 1]]
+    save("stx_general_n1024.npz", **d)
+
+
 def gen_stft():
     d = {}
     for log2n, fs in ((13, 1000.0), (13, 800.0), (16, 1000.0)):
@@ -212,13 +231,15 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "medium"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "medium"] + (["large"] if a.large else [])
     if "bands" in todo:
         gen_bands()
     if "small" in todo:
         gen_small()
     if "stft" in todo:
         gen_stft()
+    if "stxgen" in todo:
+        gen_stx_general()
     if "medium" in todo:
         gen_sized(13, (3, 12), 1000.0, "medium_n8192.npz")
     if "large" in todo:

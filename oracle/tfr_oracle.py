@@ -286,6 +286,48 @@ def stx_fft(order, sig, fs, bands=None):
     return f, np.arange(n) / fs, out
 
 
+def stx_general(sig, dt, order=8.0, f_min=None, f_max=None, f_step=None, q=0.0, p=0.0, r=1.0, geometric=False,
+                inferno=False, base=G3, ref_s=1.0):
+    """General Stockwell transform for a record of 2^k points with n_fft = len(sig) (the working subset of
+    ref styx_stx.py:52-192: its n_fft=None and zero-pad paths raise TypeError upstream).
+    Returns (tfr, psd, f_stx, f_stx_fft, windows)."""
+    sig = np.asarray(sig)
+    n = len(sig)
+    fs = 1 / dt
+    cycles_m = 12.0 / 5.0 * order
+    spec = _fft(sig)
+    cat = np.concatenate([spec, spec], axis=-1)
+    freq = _sfft.fftfreq(n, dt)
+    omega_fft = 2 * np.pi * freq / fs
+    if f_min is None:
+        f_min = cycles_m / (n / fs)
+    if f_max is None:
+        f_max = fs / 2.0
+    f_start = freq[np.abs(freq - f_min).argmin()]
+    f_stop = freq[np.abs(freq - f_max).argmin()]
+    if f_step is None:
+        f_step = (f_max - f_min) * 2.0 / len(freq)
+    f_stx = np.arange(f_start, f_stop, f_step)
+    if geometric:
+        if inferno:
+            f_stx = band_frequency_low_high(order, base, ref_s, f_start, f_stop, fs)[5]
+        else:
+            f_stx = np.logspace(np.log2(f_start), np.log2(f_stop), num=int(np.log2(f_stop / f_start) * order), base=base)
+    f_snap = np.empty(len(f_stx))
+    win = np.empty((len(f_stx), n), dtype=np.complex128)
+    tfr = np.empty((len(f_stx), n), dtype=np.complex128)
+    psd = np.empty((len(f_stx), n))
+    for i, f in enumerate(f_stx):
+        k = np.abs(freq - f).argmin()
+        f_snap[i] = freq[k]
+        w = 2 * np.pi * f_snap[i] / fs
+        sigma = cycles_m / w * ((1 + q * (w ** p)) * (w ** (1 - r)))
+        win[i] = np.exp(-0.5 * (sigma ** 2.0) * (omega_fft ** 2.0))
+        tfr[i] = _ifft(cat[k : k + n] * win[i])
+        psd[i] = np.abs(tfr[i]) ** 2 + EPS64
+    return tfr, psd, f_stx, f_snap, win
+
+
 # --------------------------------------------------------------------------- cwt_atoms
 def chirp_mqg_from_n(order, index_shift=0.0, base=G2):
     """(M_q, Q, gamma).  ref: cwt_atoms.py:122-144."""

@@ -351,3 +351,27 @@ def test_streaming_chunks_float64():
     for i, band in resumed.items():
         assert torch.equal(band, seen[i][1])
     plan.close()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("lin", dict(frequency_min=20.0, frequency_max=400.0, frequency_step=20.0)),
+    ("geo", dict(scale_order_input=3.0, frequency_min=10.0, frequency_max=450.0, is_geometric=True)),
+    ("inferno", dict(scale_order_input=3.0, frequency_min=8.0, frequency_max=400.0, is_geometric=True, is_inferno=True)),
+    ("qpr", dict(frequency_min=25.0, frequency_max=300.0, frequency_step=25.0, factor_q=0.5, power_p=1.0, power_r=0.75)),
+])
+def test_general_stockwell_vs_reference(golden, name, kw):
+    """styx_stx.tfr_stx_fft: band / bin selection bit-exact, coefficients to the float64 tolerance."""
+    g = golden("stx_general_n1024.npz")
+    tfr, psd, f, f_fft, win = styx_stx.tfr_stx_fft(g["sig"], 1 / 1000.0, n_fft_in=1024, **kw)
+    assert np.array_equal(f, g[f"{name}_f"]) and np.array_equal(f_fft, g[f"{name}_ffft"])
+    assert relmax(tfr, g[f"{name}_tfr"]) <= 1e-10
+    assert np.allclose(psd[0], g[f"{name}_psd_row0"], rtol=1e-8, atol=1e-12 * psd.max())
+    assert relmax(win[[0, len(f) - 1]], g[f"{name}_win_rows"]) <= 1e-12
+    # the padding path the reference documents but cannot run (TypeError upstream): 1000 samples padded to 1024
+    short = g["sig"][:1000]
+    t2 = styx_stx.tfr_stx_fft(short, 1 / 1000.0, n_fft_in=1024, **kw)[0]
+    ref = orc.stx_general(np.concatenate([short, np.zeros(24)]), 1 / 1000.0, **{
+        dict(scale_order_input="order", frequency_min="f_min", frequency_max="f_max", frequency_step="f_step",
+             factor_q="q", power_p="p", power_r="r", is_geometric="geometric", is_inferno="inferno")[k]: v
+        for k, v in kw.items()})[0][:, :1000]
+    assert t2.shape == ref.shape and relmax(t2, ref) <= 1e-10

@@ -145,3 +145,21 @@ def test_medium_digests(golden):
         c, _, _, fc = orc.cwt_chirp_fft(sig, 1000.0, order)
         assert np.array_equal(fc, g[f"chirp_f_o{order}"])
         assert relmax(c[g[f"chirp_rowsel_o{order}"]], g[f"chirp_rows_o{order}"]) < 1e-10
+
+
+CASES_STX_GENERAL = {
+    "lin": dict(f_min=20.0, f_max=400.0, f_step=20.0),
+    "geo": dict(order=3.0, f_min=10.0, f_max=450.0, geometric=True),
+    "inferno": dict(order=3.0, f_min=8.0, f_max=400.0, geometric=True, inferno=True),
+    "qpr": dict(f_min=25.0, f_max=300.0, f_step=25.0, q=0.5, p=1.0, r=0.75),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES_STX_GENERAL))
+def test_stx_general(golden, name):
+    g = golden("stx_general_n1024.npz")
+    tfr, psd, f, f_fft, win = orc.stx_general(g["sig"], 1 / 1000.0, **CASES_STX_GENERAL[name])
+    assert np.array_equal(f, g[f"{name}_f"]) and np.array_equal(f_fft, g[f"{name}_ffft"])
+    assert relmax(tfr, g[f"{name}_tfr"]) < 1e-14
+    assert np.allclose(psd[0], g[f"{name}_psd_row0"], rtol=1e-12)
+    assert np.array_equal(win[[0, len(f) - 1]], g[f"{name}_win_rows"])
