@@ -152,6 +152,13 @@ int qi_stft(int dtype, int device, const void* sig, int64_t n_channels, int64_t 
             int64_t hop, int64_t nfft, double scale, void* Z, void* bits, double eps, void* scratch,
             int64_t scratch_bytes, qi_stream stream);
 
+/* styx_fft.welch_power_pow2 (styx_fft.py:230-266): scipy.signal.welch, detrend="constant", scaling="spectrum",
+ * average="mean", one-sided, no boundary extension.  Pxx: [C][nfft/2+1] real.  scale = 1/sum(window). */
+int64_t qi_welch_scratch_bytes(int dtype, int64_t n_channels, int64_t n, int64_t seg, int64_t hop, int64_t nfft);
+int qi_welch(int dtype, int device, const void* sig, int64_t n_channels, int64_t n, const void* window, int64_t seg,
+             int64_t hop, int64_t nfft, double scale, void* pxx, void* scratch, int64_t scratch_bytes,
+             qi_stream stream);
+
 /* ---- tfr_info reductions on a caller-supplied power panel P [C][B][n] (real) ---------- */
 /* Marginals in one pass: power_band [C][B] f64, power_time [C][n] real, stats [C][4] f64
  * {max, sum, sum P log2 P, 0}.  tfr_info.py:82-94 (the sums / max under the log2). */

@@ -174,6 +174,12 @@ def gen_stft():
                 d[f"f_{tag}_o{order}"] = f
                 d[f"shape_{tag}_o{order}"] = np.array(z.shape)
     # stft_complex_pow2 with its own default alpha = 0.25 Tukey, 2-D input (axis -1)
+    for dtype in (np.float64, np.float32):
+        sigw = synth_chirp(8192, 1000.0, dtype=dtype)
+        fw, pw = styx_fft.welch_power_pow2(sigw, 1000.0, 512)
+        d[f"welch_f_{np.dtype(dtype).name}"], d[f"welch_p_{np.dtype(dtype).name}"] = fw, pw
+        fw, pw = styx_fft.welch_power_pow2(sigw, 1000.0, 300, nfft_points=512, overlap_points=100, alpha=0.5)
+        d[f"welch2_p_{np.dtype(dtype).name}"] = pw
     sig2 = np.stack([synth_chirp(4096, 1000.0, c, 3, np.float64) for c in range(3)])
     f, t, z = styx_fft.stft_complex_pow2(sig2, 1000.0, 256)
     d["sig_2d"], d["z_2d_alpha025"], d["t_2d"], d["f_2d"] = sig2, z, t, f

@@ -219,6 +219,34 @@ def stft_from_sig(sig, fs, order, center_hz=None, octaves_below=4):
     return z, to_log2_with_epsilon(z), t, f
 
 
+def welch_power_pow2(sig, fs, seg, nfft=None, overlap=None, alpha=0.25):
+    """scipy.signal.welch(window=("tukey", alpha), detrend="constant", scaling="spectrum", average="mean",
+    return_onesided=True) restated (SciPy 1.15.3 _spectral_helper with boundary=None, padded=False).
+    ref: styx_fft.py:230-266."""
+    x = np.asarray(sig)
+    if nfft is None:
+        nfft = int(2 ** np.ceil(np.log2(seg)))
+    if overlap is None:
+        overlap = int(seg / 2)
+    out_dtype = np.result_type(x, np.complex64)
+    step = seg - overlap
+    win = tukey_periodic(seg, alpha)
+    if np.result_type(win, np.complex64) != out_dtype:
+        win = win.astype(out_dtype)
+    scale = 1.0 / win.sum() ** 2
+    frames = np.lib.stride_tricks.sliding_window_view(x, seg, axis=-1)[..., 0::step, :]
+    frames = frames - np.mean(frames, axis=-1, keepdims=True)
+    frames = (win * frames).real
+    spec = _rfft(frames, n=nfft, axis=-1)
+    p = np.conjugate(spec) * spec * scale
+    if nfft % 2:
+        p[..., 1:] *= 2
+    else:
+        p[..., 1:-1] *= 2
+    p = p.astype(out_dtype).real
+    return np.fft.rfftfreq(nfft, 1 / fs), p.mean(axis=-2)
+
+
 # --------------------------------------------------------------------------- styx_cwt
 def wavelet_amplitude(scale):
     """ref: styx_cwt.py:29-40."""

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "qi_stft_segments": (_i64, [_i64, _i64, _i64]),
     "qi_stft_scratch_bytes": (_i64, [_int, _i64, _i64, _i64, _i64, _i64]),
     "qi_stft": (_int, [_int, _int, _P, _i64, _i64, _P, _i64, _i64, _i64, _dbl, _P, _P, _dbl, _P, _i64, _P]),
+    "qi_welch_scratch_bytes": (_i64, [_int, _i64, _i64, _i64, _i64, _i64]),
+    "qi_welch": (_int, [_int, _int, _P, _i64, _i64, _P, _i64, _i64, _i64, _dbl, _P, _P, _i64, _P]),
     "qi_power_marginals": (_int, [_int, _int, _P, _i64, _i64, _i64, _P, _P, _P, _P, _i64, _P]),
     "qi_power_marginals_scratch_bytes": (_i64, [_i64, _i64, _i64]),
     "qi_log2_offset": (_int, [_int, _int, _P, _P, _i64, _i64, _dbl, _P, _P]),

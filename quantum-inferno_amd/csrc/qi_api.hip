@@ -796,13 +796,29 @@ int stft_impl(int device, const void* sig, int64_t C, int64_t n, const void* win
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
-                               nfft, nseg, st));
+                               nfft, nseg, seg / 2, st));
   {
     std::lock_guard<std::mutex> lk(g_stft_mu);
     QI_TRY(fft_r2c<T>(g_stft_fft[device], frames, F, nfft, C * nseg, st));
   }
   return launch_stft_transpose<T>(F, static_cast<cplx<T>*>(Z), static_cast<T*>(bits), C, nseg, nf, (T)scale,
                                   (T)(eps == 0.0 ? 2.220446049250313e-16 : eps), st);
+}
+
+template <typename T>
+int welch_impl(int device, const void* sig, int64_t C, int64_t n, const void* window, int64_t seg, int64_t hop,
+               int64_t nfft, double scale, void* pxx, char* scratch, hipStream_t st) {
+  const int64_t nseg = (n - seg) / hop + 1;
+  const int64_t nf = nfft / 2 + 1;
+  T* frames = reinterpret_cast<T*>(scratch);
+  cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
+  QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
+                               nfft, nseg, 0, st));
+  {
+    std::lock_guard<std::mutex> lk(g_stft_mu);
+    QI_TRY(fft_r2c<T>(g_stft_fft[device], frames, F, nfft, C * nseg, st));
+  }
+  return launch_welch_mean<T>(F, static_cast<T*>(pxx), C, nseg, nf, nfft, (T)(scale * scale), st);
 }
 
 }  // namespace
@@ -1115,6 +1131,27 @@ int qi_stft(int dtype, int device, const void* sig, int64_t C, int64_t n, const 
                                              (char*)scratch, (hipStream_t)stream)
                          : stft_impl<float>(device, sig, C, n, window, seg, hop, nfft, scale, Z, bits, eps,
                                             (char*)scratch, (hipStream_t)stream);
+}
+
+int64_t qi_welch_scratch_bytes(int dtype, int64_t C, int64_t n, int64_t seg, int64_t hop, int64_t nfft) {
+  if (n < seg || seg <= 0 || hop <= 0) return 0;
+  const int64_t nseg = (n - seg) / hop + 1;
+  const size_t e = dtype == QI_F64 ? 8 : 4;
+  return (int64_t)(align_up((size_t)C * nseg * nfft * e) + align_up((size_t)C * nseg * (nfft / 2 + 1) * 2 * e));
+}
+
+int qi_welch(int dtype, int device, const void* sig, int64_t C, int64_t n, const void* window, int64_t seg,
+             int64_t hop, int64_t nfft, double scale, void* pxx, void* scratch, int64_t scratch_bytes,
+             qi_stream stream) {
+  QI_REQUIRE(sig && window && pxx && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && seg > 0 && n >= seg && hop > 0 && hop <= seg && nfft >= seg, "bad Welch geometry");
+  QI_REQUIRE(scratch_bytes >= qi_welch_scratch_bytes(dtype, C, n, seg, hop, nfft), "scratch too small");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? welch_impl<double>(device, sig, C, n, window, seg, hop, nfft, scale, pxx, (char*)scratch,
+                                              (hipStream_t)stream)
+                         : welch_impl<float>(device, sig, C, n, window, seg, hop, nfft, scale, pxx, (char*)scratch,
+                                             (hipStream_t)stream);
 }
 
 // ---- tfr_info -------------------------------------------------------------------------------------

@@ -125,7 +125,10 @@ int launch_finalize(const double* part_band, const double* part_stat, double* po
 
 template <typename T>
 int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
-                       int64_t nfft, int64_t nseg, hipStream_t st);
+                       int64_t nfft, int64_t nseg, int64_t lead, hipStream_t st);
+template <typename T>
+int launch_welch_mean(const cplx<T>* F, T* pxx, int64_t C, int64_t nseg, int64_t nf, int64_t nfft, T scale2,
+                      hipStream_t st);
 template <typename T>
 int launch_stft_transpose(const cplx<T>* F, cplx<T>* Z, T* bits, int64_t C, int64_t nseg, int64_t nf, T scale, T eps,
                           hipStream_t st);

@@ -222,12 +222,12 @@ __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ par
 template <typename T>
 __global__ void __launch_bounds__(256) k_stft_frames(const T* __restrict__ sig, const T* __restrict__ win,
                                                      T* __restrict__ frames, int64_t n, int64_t seg, int64_t hop,
-                                                     int64_t nfft, int64_t nseg) {
+                                                     int64_t nfft, int64_t nseg, int64_t lead) {
   __shared__ double s[256 / kWave];
   __shared__ double s_mean;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t m = blockIdx.x, c = blockIdx.y;
-  const int64_t base = m * hop - seg / 2;
+  const int64_t base = m * hop - lead;  // lead = seg/2 zero-extended samples (stft) or 0 (welch)
   const T* x = sig + c * n;
   double acc = 0.0;
   for (int64_t i = tid; i < seg; i += 256) {
@@ -278,6 +278,22 @@ __global__ void k_stft_transpose(const cplx<T>* __restrict__ F, cplx<T>* __restr
       if (bits) bits[(c * nf + f) * nseg + m] = log2_t(sqrt_t(z.x * z.x + z.y * z.y) + eps);
     }
   }
+}
+
+// Welch: Pxx[c][f] = w_f * scale^2 * mean over segments of |F[c][m][f]|^2, w_f = 2 except at DC and (even nfft) Nyquist
+// (scipy.signal.welch, scaling="spectrum", average="mean", one-sided; call site styx_fft.py:253-266).
+template <typename T>
+__global__ void k_welch_mean(const cplx<T>* __restrict__ F, T* __restrict__ pxx, int64_t nseg, int64_t nf, int64_t nfft,
+                             T scale2) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (f >= nf) return;
+  double acc = 0.0;
+  for (int64_t m = 0; m < nseg; ++m) {
+    const cplx<T> z = F[(c * nseg + m) * nf + f];
+    acc += (double)(z.x * z.x + z.y * z.y);
+  }
+  const bool paired = f > 0 && !(nfft % 2 == 0 && f == nf - 1);
+  pxx[c * nf + f] = (T)(acc / (double)nseg) * scale2 * (paired ? T(2) : T(1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,9 +398,9 @@ int launch_finalize(const double* part_band, const double* part_stat, double* po
 
 template <typename T>
 int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
-                       int64_t nfft, int64_t nseg, hipStream_t st) {
+                       int64_t nfft, int64_t nseg, int64_t lead, hipStream_t st) {
   dim3 g((unsigned)nseg, (unsigned)C);
-  k_stft_frames<T><<<g, 256, 0, st>>>(sig, win, frames, n, seg, hop, nfft, nseg);
+  k_stft_frames<T><<<g, 256, 0, st>>>(sig, win, frames, n, seg, hop, nfft, nseg, lead);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
@@ -394,6 +410,15 @@ int launch_stft_transpose(const cplx<T>* F, cplx<T>* Z, T* bits, int64_t C, int6
                           hipStream_t st) {
   dim3 g((unsigned)ceil_div(nf, 32), (unsigned)ceil_div(nseg, 32), (unsigned)C);
   k_stft_transpose<T><<<g, dim3(32, 8), 0, st>>>(F, Z, bits, nseg, nf, scale, eps);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <typename T>
+int launch_welch_mean(const cplx<T>* F, T* pxx, int64_t C, int64_t nseg, int64_t nf, int64_t nfft, T scale2,
+                      hipStream_t st) {
+  dim3 g((unsigned)ceil_div(nf, 256), (unsigned)C);
+  k_welch_mean<T><<<g, 256, 0, st>>>(F, pxx, nseg, nf, nfft, scale2);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
@@ -454,7 +479,8 @@ int launch_shannon(const T* P, const T* mult, int mode, int64_t C, int64_t B, in
                                     const double*, hipStream_t);                                                   \
   template int launch_epilogue<T>(const EpiArgs<T>&, hipStream_t);                                                 \
   template int launch_stft_frames<T>(const T*, const T*, T*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, \
-                                     hipStream_t);                                                                 \
+                                     int64_t, hipStream_t);                                                        \
+  template int launch_welch_mean<T>(const cplx<T>*, T*, int64_t, int64_t, int64_t, int64_t, T, hipStream_t);       \
   template int launch_stft_transpose<T>(const cplx<T>*, cplx<T>*, T*, int64_t, int64_t, int64_t, T, T,             \
                                         hipStream_t);                                                              \
   template int launch_power_marginals<T>(const T*, int64_t, int64_t, int64_t, T*, double*, double*, hipStream_t);  \

@@ -141,3 +141,41 @@ def stft_from_sig(
         want_bits=True,
     )
     return z, bits, t, f
+
+
+def welch_power_pow2(
+    sig_wf,
+    frequency_sample_rate_hz: float,
+    segment_points: int,
+    nfft_points: int = None,
+    overlap_points: int = None,
+    alpha: float = 0.25,
+):
+    """Welch power spectrum: mean over 50 %-overlapped Tukey segments of the one-sided |FFT|^2, "spectrum" scaling
+    (ref styx_fft.py:230-266).  :return: frequency_welch_hz, welch_power [nfft/2+1] (or [channels x ...])"""
+    lib = _lib.require_gpu()
+    if nfft_points is None:
+        nfft_points = int(2 ** np.ceil(np.log2(segment_points)))
+    if overlap_points is None:
+        overlap_points = int(segment_points / 2)
+    sig, was_numpy, was_1d = engine.as_signal(sig_wf)
+    n_ch, n = sig.shape
+    seg, nfft = int(segment_points), int(nfft_points)
+    hop = seg - int(overlap_points)
+    if n < seg:
+        raise ValueError(f"Signal length: {n} is less than the segment: {seg}")
+    if not 0 < hop <= seg:
+        raise ValueError("noverlap must be less than nperseg.")
+    f64 = sig.dtype == torch.float64
+    win64 = tukey_window_periodic(seg, alpha)
+    win = win64 if f64 else win64.astype(np.float32)
+    scale = float(1.0 / np.sum(win.astype(np.float64)))
+    win_d = torch.from_numpy(np.ascontiguousarray(win)).to(sig.device)
+    code = _lib.QI_F64 if f64 else _lib.QI_F32
+    pxx = torch.empty((n_ch, nfft // 2 + 1), dtype=sig.dtype, device=sig.device)
+    nbytes = int(lib.qi_welch_scratch_bytes(code, n_ch, n, seg, hop, nfft))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=sig.device)
+    with torch.cuda.device(sig.device):
+        _lib.check(lib.qi_welch(code, sig.device.index, _lib.ptr(sig), n_ch, n, _lib.ptr(win_d), seg, hop, nfft, scale,
+                                _lib.ptr(pxx), _lib.ptr(scratch), nbytes, _lib.stream_ptr(sig.device)))
+    return np.fft.rfftfreq(nfft, 1 / frequency_sample_rate_hz), engine.finish(pxx, was_numpy, was_1d)

@@ -375,3 +375,20 @@ def test_general_stockwell_vs_reference(golden, name, kw):
              factor_q="q", power_p="p", power_r="r", is_geometric="geometric", is_inferno="inferno")[k]: v
         for k, v in kw.items()})[0][:, :1000]
     assert t2.shape == ref.shape and relmax(t2, ref) <= 1e-10
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_welch_vs_reference(golden, dtype):
+    """styx_fft.welch_power_pow2."""
+    g = golden("stft.npz")
+    sig = g[f"sig_n13_fs1000_{dtype}"]
+    tol = 1e-10 if dtype == "float64" else 2e-5
+    f, p = styx_fft.welch_power_pow2(sig, 1000.0, 512)
+    assert np.array_equal(f, g[f"welch_f_{dtype}"]) and p.dtype == g[f"welch_p_{dtype}"].dtype
+    assert relmax(p, g[f"welch_p_{dtype}"]) <= tol
+    _, p2 = styx_fft.welch_power_pow2(sig, 1000.0, 300, nfft_points=512, overlap_points=100, alpha=0.5)
+    assert relmax(p2, g[f"welch2_p_{dtype}"]) <= tol
+    _, pb = styx_fft.welch_power_pow2(np.stack([sig, 2 * sig]), 1000.0, 512)
+    assert pb.shape == (2, 257) and relmax(pb[1], 4 * g[f"welch_p_{dtype}"]) <= tol
+    with pytest.raises(ValueError):
+        styx_fft.welch_power_pow2(sig[:100], 1000.0, 512)

@@ -163,3 +163,14 @@ def test_stx_general(golden, name):
     assert relmax(tfr, g[f"{name}_tfr"]) < 1e-14
     assert np.allclose(psd[0], g[f"{name}_psd_row0"], rtol=1e-12)
     assert np.array_equal(win[[0, len(f) - 1]], g[f"{name}_win_rows"])
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_welch(golden, dtype):
+    g = golden("stft.npz")
+    sig = g[f"sig_n13_fs1000_{dtype}"]
+    f, p = orc.welch_power_pow2(sig, 1000.0, 512)
+    assert np.array_equal(f, g[f"welch_f_{dtype}"]) and p.dtype == g[f"welch_p_{dtype}"].dtype
+    assert np.allclose(p, g[f"welch_p_{dtype}"], rtol=1e-12 if dtype == "float64" else 2e-6, atol=0)
+    _, p2 = orc.welch_power_pow2(sig, 1000.0, 300, nfft=512, overlap=100, alpha=0.5)
+    assert np.allclose(p2, g[f"welch2_p_{dtype}"], rtol=1e-12 if dtype == "float64" else 2e-6, atol=0)
