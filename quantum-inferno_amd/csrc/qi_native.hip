@@ -2,9 +2,9 @@
 //
 // An inverse FFT of length Lf = N1 * N2 (N2 = 1024) is evaluated as out[t1 + N1 t2] =
 //   sum_k2 A[t1][k2] W_N2^(k2 t2),   A[t1][k2] = sum_{k == k2 mod N2} Y[k] W_Lf^(k t1).
-// One workgroup owns G consecutive t1 (so every store is a run of G consecutive time samples),
-// holds the G rows of N2 points in LDS, transforms them with two register radix-32 steps and one
-// LDS exchange, and applies the crop / power / entropy epilogue from registers.
+// One workgroup (1024 threads, 64 per row) owns G = 16 consecutive t1 (so every store is a run of 16 consecutive
+// time samples), transforms the 16 rows of N2 points as 16 x 16 x 4 with one exchange through LDS, and applies the
+// crop / power / entropy epilogue from registers.
 //  * A band whose spectrum product Y has a short support (a Gaussian atom far from DC) gets A
 //    straight from the spectrum: "pruned" loader, no intermediate in HBM at all.
 //  * A wide band goes through pass 1 (the same row kernel over k1 for G1 consecutive k2) which writes
@@ -96,16 +96,19 @@ __device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double
   *s = sf;
 }
 
-// Geometry of one workgroup: G rows of 1024 points, 32 threads per row.
-template <typename T, int G_, bool DFAST_>
+// Geometry of one workgroup: G = 16 rows of 1024 points, 64 threads per row (1024 threads = 16 waves, <= 128 VGPRs:
+// four waves per SIMD).  The 1024-point row transform is 16 x 16 x 4: step 1, thread (row g, a) transforms
+// x[a + 64 b] over b; after the exchange through LDS, thread (d, c2, row g) -- wave = d, lanes = (c2, g) so that
+// stores run over the 16 rows -- folds the radix-4 over q (a = a1 + 16 q) for its own c2 and transforms over a1.
+template <typename T>
 struct Cfg {
-  static constexpr int NR = 1024, G = G_, TH = 32 * G_;
-  static constexpr bool DFAST = DFAST_;   // step-2 lanes run over d (pass 1: rows are contiguous in t1) or over g
-  static constexpr int SR = NR + 1;       // row stride of the natural-order image A[g][k]
-  static constexpr int SA = 32 * G_ + 1;  // a-stride of the exchange image E[a][...]
-  static constexpr int BUF = (G_ * SR > 32 * SA) ? G_ * SR : 32 * SA;
-  static constexpr int TW1 = (kMaxPrunedTerms + 1) * G_;  // inner twiddles of the pruned loader
-  static constexpr size_t LDS_BYTES = ((size_t)BUF + NR + TW1) * sizeof(cplx<T>) + 256;
+  static constexpr int NR = 1024, G = 16, TH = 1024;
+  static constexpr int SR = NR + 1;      // row stride of the natural-order image A[g][k]
+  static constexpr int SA = 16 * G + 1;  // a-stride of the exchange image E[a][d][g]
+  static constexpr int BUF = (G * SR > 64 * SA) ? G * SR : 64 * SA;
+  static constexpr int TW1 = (kMaxPrunedTerms + 1) * G;  // inner twiddles of the pruned loader
+  static constexpr int TW2 = 64;                         // W_64^(a1 c2)
+  static constexpr size_t LDS_BYTES = ((size_t)BUF + NR + TW2 + TW1) * sizeof(cplx<T>) + 256;
 };
 
 #ifdef QI_NATIVE_DEBUG
@@ -142,7 +145,7 @@ template <typename T, class C, bool STX>
 __device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowArgs<T>& a, const BandDesc& bd,
                                             const cplx<T>* __restrict__ X, uint32_t t1_0) {
   constexpr int MAXM = kMaxPrunedTerms + 1;  // distinct k1 = floor(k / 1024) a support of <= 8192 bins can touch
-  constexpr int SPT = C::NR / C::TH;         // slots per thread
+  constexpr int SPT = C::NR / C::TH;         // slots per thread (1)
   const int tid = threadIdx.x;
   const uint32_t mask = (uint32_t)a.Lf - 1u;  // Lf is a power of two: x mod Lf == x & mask, also for negative x
   const int32_t k_end = bd.k_lo + bd.k_len;
@@ -227,14 +230,13 @@ __device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowA
   }
 }
 
-// general pass 2: the intermediate is stored transposed, imdT[r][k2] (one 8 KB row per time residue), so a thread
-// of row g takes its 32 step-1 inputs k2 = a + 32 b straight into registers: 256-byte runs per row, no LDS image,
-// no barrier
+// general pass 2: the intermediate is stored transposed, imdT[r][k2] (one 8 KB row per time residue), so thread
+// (row g, a) takes its 16 step-1 inputs k2 = a + 64 b straight into registers: 512-byte runs per row, no LDS image
 template <typename T>
-__device__ __forceinline__ void load_imd_direct(cplx<T> (&v)[32], const cplx<T>* __restrict__ imdT, uint32_t row, int a1) {
+__device__ __forceinline__ void load_imd_direct(cplx<T> (&v)[16], const cplx<T>* __restrict__ imdT, uint32_t row, int a1) {
   const cplx<T>* __restrict__ src = imdT + (size_t)row * kN2 + a1;
 #pragma unroll
-  for (int b = 0; b < 32; ++b) v[b] = src[32 * b];
+  for (int b = 0; b < 16; ++b) v[b] = src[64 * b];
 }
 
 // pass-1 operand Y[k] of one band: spectrum x stored bank row (SRC 0), shifted spectrum x Gaussian (SRC 1), or the
@@ -298,36 +300,41 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
   }
 }
 
-// tw[d * 32 + a] = W_1024^(a d): the twiddle between the two radix-32 steps, lanes run over a
+// tw[d * 64 + a] = W_1024^(a d) (between step 1 and step 2, lanes run over a) and tw[1024 + c2 * 16 + a1] =
+// W_64^(a1 c2) (inside step 2)
 template <typename T, class C>
 __device__ __forceinline__ void fill_step_twiddles(cplx<T>* tw) {
-  for (int i = threadIdx.x; i < C::NR; i += C::TH) {
-    const int d = i / 32, aa = i % 32;
+  for (int i = threadIdx.x; i < C::NR + C::TW2; i += C::TH) {
     float sf, cf;
-    sincospif((float)(2 * (aa * d)) / (float)C::NR, &sf, &cf);
+    if (i < C::NR) {
+      const int d = i / 64, aa = i % 64;
+      sincospif((float)(2 * (aa * d)) / (float)C::NR, &sf, &cf);
+    } else {
+      const int c2 = (i - C::NR) / 16, a1 = (i - C::NR) % 16;
+      sincospif((float)(2 * (a1 * c2)) / 64.0f, &sf, &cf);
+    }
     tw[i] = mk<T>((T)cf, (T)sf);
   }
 }
 
-// 1024-point inverse transform of G rows, all threads of the workgroup: two register radix-32 steps and one exchange
-// through LDS.  Thread (g1, a1) enters with its 32 step-1 inputs x[a1 + 32 b] of row g1 in v (from the LDS image or
-// straight from global memory); on return thread (g2, d2) holds out[d2 + 32 c] in u[brev(c, 5)] and buf is free.
-// `between` runs on every thread right after the first barrier (used to flush a pending reduction).
-template <typename T, class C, class F>
-__device__ __forceinline__ void rows_fft1024_regs(cplx<T> (&v)[32], cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[32],
-                                                  bool skip, F between
+// 1024-point inverse transform of G rows, all threads of the workgroup.  Thread (g1 = tid / 64, a1 = tid % 64) enters
+// with its 16 step-1 inputs x[a1 + 64 b] of row g1 in v; on return thread (d2 = tid / 64, c2 = (tid % 64) / 16,
+// g2 = tid % 16) holds out[d2 + 16 c2 + 64 c1] of row g2 in u[brev(c1, 4)] and buf is free.  `between` runs on every
+// thread right after the first barrier (flush of a pending reduction), `before_step2` after the last one.
+template <typename T, class C, class F, class F2>
+__device__ __forceinline__ void rows_fft1024_regs(cplx<T> (&v)[16], cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[16],
+                                                  bool skip, F between, F2 before_step2
 #ifdef QI_NATIVE_STAMPS
                                                   , unsigned long long (&st_acc)[8], unsigned long long& st_last
 #endif
 ) {
   const int tid = threadIdx.x;
-  const int g1 = tid / 32, a1 = tid % 32;
-  const int g2 = C::DFAST ? tid / 32 : tid % C::G;
-  const int d2 = C::DFAST ? tid % 32 : tid / C::G;
+  const int g1 = tid / 64, a1 = tid % 64;
+  const int d2 = tid / 64, lane = tid % 64, c2 = lane / 16, g2 = lane % 16;
   if (!skip) {
-    fft_reg<T, 32, 1>(v);
+    fft_reg<T, 16, 1>(v);
 #pragma unroll
-    for (int d = 1; d < 32; ++d) v[brev(d, 5)] = cmul(v[brev(d, 5)], tw[d * 32 + a1]);
+    for (int d = 1; d < 16; ++d) v[brev(d, 4)] = cmul(v[brev(d, 4)], tw[d * 64 + a1]);
   }
   __builtin_amdgcn_sched_barrier(0);
   QI_STAMP(2);
@@ -335,35 +342,48 @@ __device__ __forceinline__ void rows_fft1024_regs(cplx<T> (&v)[32], cplx<T>* buf
   QI_STAMP(3);
   between();
 #pragma unroll
-  for (int d = 0; d < 32; ++d) buf[a1 * C::SA + (C::DFAST ? g1 * 32 + d : d * C::G + g1)] = v[brev(d, 5)];
+  for (int d = 0; d < 16; ++d) buf[a1 * C::SA + d * C::G + g1] = v[brev(d, 4)];
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
-  // step 2: per row 32 transforms over a
+  // step 2: X[d + 16 (c2 + 4 c1)] = sum_a1 W_16^(a1 c1) W_64^(a1 c2) sum_q T'[a1 + 16 q][d] W_4^(q c2)
+  const T sg = (c2 & 1) ? T(-1) : T(1), tau = (c2 & 2) ? T(-1) : T(1);
+  const bool odd = c2 & 1;
+  const cplx<T>* __restrict__ col = buf + d2 * C::G + g2;
 #pragma unroll
-  for (int aa = 0; aa < 32; ++aa) u[aa] = buf[aa * C::SA + (C::DFAST ? g2 * 32 + d2 : d2 * C::G + g2)];
+  for (int a = 0; a < 16; ++a) {
+    const cplx<T> t0 = col[a * C::SA], t1 = col[(a + 16) * C::SA], t2 = col[(a + 32) * C::SA], t3 = col[(a + 48) * C::SA];
+    const cplx<T> u02 = mk<T>(t0.x + sg * t2.x, t0.y + sg * t2.y), u13 = mk<T>(t1.x + sg * t3.x, t1.y + sg * t3.y);
+    const cplx<T> w13 = odd ? mk<T>(-u13.y, u13.x) : u13;  // times i for the odd residues
+    u[a] = mk<T>(u02.x + tau * w13.x, u02.y + tau * w13.y);
+  }
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   QI_STAMP(4);
-  if (!skip) fft_reg<T, 32, 1>(u);
+  before_step2();
+  if (!skip) {
+#pragma unroll
+    for (int a = 1; a < 16; ++a) u[a] = cmul(u[a], tw[C::NR + c2 * 16 + a]);
+    fft_reg<T, 16, 1>(u);
+  }
   __builtin_amdgcn_sched_barrier(0);
   QI_STAMP(5);
 }
 
 // same, starting from the natural-order LDS image A[g][k] (row stride SR) the caller filled and synchronised
 template <typename T, class C>
-__device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[32], bool skip
+__device__ __forceinline__ void rows_fft1024(cplx<T>* buf, const cplx<T>* tw, cplx<T> (&u)[16], bool skip
 #ifdef QI_NATIVE_STAMPS
                                              , unsigned long long (&st_acc)[8], unsigned long long& st_last
 #endif
 ) {
-  const int g1 = threadIdx.x / 32, a1 = threadIdx.x % 32;
-  cplx<T> v[32];
+  const int g1 = threadIdx.x / 64, a1 = threadIdx.x % 64;
+  cplx<T> v[16];
 #pragma unroll
-  for (int b = 0; b < 32; ++b) v[b] = buf[g1 * C::SR + a1 + 32 * b];
+  for (int b = 0; b < 16; ++b) v[b] = buf[g1 * C::SR + a1 + 64 * b];
 #ifdef QI_NATIVE_STAMPS
-  rows_fft1024_regs<T, C>(v, buf, tw, u, skip, [] {}, st_acc, st_last);
+  rows_fft1024_regs<T, C>(v, buf, tw, u, skip, [] {}, [] {}, st_acc, st_last);
 #else
-  rows_fft1024_regs<T, C>(v, buf, tw, u, skip, [] {});
+  rows_fft1024_regs<T, C>(v, buf, tw, u, skip, [] {}, [] {});
 #endif
 }
 
@@ -378,7 +398,7 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const int tid = threadIdx.x;
   const int64_t ch = blockIdx.z;
   const uint32_t row0 = blockIdx.x * C::G;
-  const int g2 = tid % C::G, d2 = tid / C::G;  // lanes run over the G rows: stores are runs of G consecutive k2
+  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;  // lanes run over the G rows: stores are runs of G k2
   fill_step_twiddles<T, C>(tw);
   BandDesc bd{};
   if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y]];
@@ -386,9 +406,9 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const T* sigc = SRC == 2 ? a.sig + ch * a.n : nullptr;
   const uint32_t mask = (uint32_t)a.Lf - 1u;
   const uint32_t k2 = row0 + g2;
-  // The linear kind's pass 2 works on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken
-  // at -1): columns are stored at r = (t1 + 1) mod N1 so that pass 2 reads aligned runs of G columns.
-  // transposed intermediate imdT[r][k2]: one row of 1024 values per time residue
+  // transposed intermediate imdT[r][k2]: one row of 1024 values per time residue.  The linear kind's pass 2 works
+  // on residues t1 = r - 1 (r = 0 is t1 = -1 == N1 - 1 with the pass twiddle taken at -1): columns are stored at
+  // r = (t1 + 1) mod N1 so that pass 2 reads whole rows.
   cplx<T>* __restrict__ dst = a.imd + ((int64_t)ch * a.imd_slots + bd.gen_slot) * a.Lf + k2;
   const uint32_t roll = a.neg_last_row ? 1u : 0u, cmask = (uint32_t)a.N1 - 1u;
 #ifdef QI_NATIVE_STAMPS
@@ -400,21 +420,21 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
     if (!QI_DBG(2)) load_full<T, C, SRC, NPH>(buf, a, bd, Xc, sigc, row0, ph);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    cplx<T> u[32];
+    cplx<T> u[16];
 #ifdef QI_NATIVE_STAMPS
     rows_fft1024<T, C>(buf, tw, u, QI_DBG(4), st_acc, st_last);
 #else
     rows_fft1024<T, C>(buf, tw, u, QI_DBG(4));
 #endif
-    // pass twiddle W_Lf^(k2 t1) along t1 = NPH (d2 + 32 c) + ph by a float64 recurrence from single-precision seeds
+    // pass twiddle W_Lf^(k2 t1) along t1 = NPH (d2 + 16 c2 + 64 c1) + ph by a float64 recurrence over c1
     double wr, wi, sr, si;
-    unit_root((k2 * (uint32_t)(NPH * d2 + ph)) & mask, a.two_over_len, &wr, &wi);
-    unit_root((k2 * (uint32_t)(32 * NPH)) & mask, a.two_over_len, &sr, &si);
+    unit_root((k2 * (uint32_t)(NPH * (d2 + 16 * c2) + ph)) & mask, a.two_over_len, &wr, &wi);
+    unit_root((k2 * (uint32_t)(64 * NPH)) & mask, a.two_over_len, &sr, &si);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      const cplx<T> z = u[brev(c, 5)];
-      const uint32_t t1 = (uint32_t)(NPH * (d2 + 32 * c)) + (uint32_t)ph;
-      if (c == 31 && a.neg_last_row && t1 == cmask)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
+    for (int c1 = 0; c1 < 16; ++c1) {
+      const cplx<T> z = u[brev(c1, 4)];
+      const uint32_t t1 = (uint32_t)(NPH * (d2 + 16 * c2 + 64 * c1)) + (uint32_t)ph;
+      if (c1 == 15 && a.neg_last_row && t1 == cmask)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
         unit_root((0u - k2) & mask, a.two_over_len, &wr, &wi);
       const T cr = (T)wr, ci = (T)wi;
       if (!QI_DBG(1)) dst[(size_t)((t1 + roll) & cmask) * kN2] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
@@ -437,24 +457,24 @@ __global__ void __launch_bounds__(C::TH) k_fwd2(RowArgs<T> a, cplx<T>* __restric
   const int tid = threadIdx.x;
   const int64_t ch = blockIdx.z;
   const uint32_t row0 = blockIdx.x * C::G;
-  const int g2 = tid % C::G, d2 = tid / C::G;
+  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;
   fill_step_twiddles<T, C>(tw);
-  cplx<T> v[32], u[32];
-  load_imd_direct<T>(v, a.imd + (int64_t)ch * a.imd_slots * a.Lf, row0 + tid / 32, tid % 32);
+  cplx<T> v[16], u[16];
+  load_imd_direct<T>(v, a.imd + (int64_t)ch * a.imd_slots * a.Lf, row0 + tid / 64, tid % 64);
   __syncthreads();  // step twiddles ready
 #ifdef QI_NATIVE_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = 0;
-  rows_fft1024_regs<T, C>(v, buf, tw, u, false, [] {}, st_acc, st_last);
+  rows_fft1024_regs<T, C>(v, buf, tw, u, false, [] {}, [] {}, st_acc, st_last);
 #else
-  rows_fft1024_regs<T, C>(v, buf, tw, u, false, [] {});
+  rows_fft1024_regs<T, C>(v, buf, tw, u, false, [] {}, [] {});
 #endif
-  cplx<T>* __restrict__ dst = Xout + ch * a.Lf + row0 + g2 + (uint32_t)a.N1 * d2;
-  const uint32_t tstep = 32u * (uint32_t)a.N1;
+  cplx<T>* __restrict__ dst = Xout + ch * a.Lf + row0 + g2 + (uint32_t)a.N1 * (d2 + 16 * c2);
+  const uint32_t tstep = 64u * (uint32_t)a.N1;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const cplx<T> z = u[brev(c, 5)];
-    dst[(size_t)c * tstep] = mk<T>(z.x, -z.y);
+  for (int c1 = 0; c1 < 16; ++c1) {
+    const cplx<T> z = u[brev(c1, 4)];
+    dst[(size_t)c1 * tstep] = mk<T>(z.x, -z.y);
   }
 }
 
@@ -462,13 +482,13 @@ __global__ void __launch_bounds__(C::TH) k_fwd2(RowArgs<T> a, cplx<T>* __restric
 // Rows are G consecutive time residues t1; the transform runs over k2 and the epilogue crops / rolls into the
 // panel and takes the tfr_info reductions from registers.
 // KIND: 0 zero-padded linear correlation (Lf = 2n, keep [n/2 - 1, n/2 - 1 + n)), 1 circular correlation rolled by
-// n/2 (Lf = n), 2 Stockwell (Lf = n).  With t = t1 + N1 (d + 32 c) the crop / roll is a compile-time map of c:
-//   KIND 2: panel position i = c;  KIND 1: i = (c + 16) mod 32;  KIND 0: i = c - 8 for c in [8, 24) (16 of the 32
-//   outputs of a thread are kept, the others are never computed: the dead butterflies are eliminated).
+// n/2 (Lf = n), 2 Stockwell (Lf = n).  With t = t1 + N1 (d + 16 c2 + 64 c1) the crop / roll is a compile-time map
+// of c1:  KIND 2: panel position i = c1;  KIND 1: i = (c1 + 8) mod 16;  KIND 0: i = c1 - 4 for c1 in [4, 12) (8 of
+// the 16 outputs of a thread are kept, the others are never computed: the dead butterflies are eliminated).
 template <typename T, class C, int KIND, bool COEF, bool BITS>
 __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   constexpr bool STX = KIND == 2;
-  constexpr int NOUT = KIND == 0 ? 16 : 32;
+  constexpr int NOUT = KIND == 0 ? 8 : 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   cplx<T>* buf = reinterpret_cast<cplx<T>*>(smem);
   cplx<T>* tw = buf + C::BUF;
@@ -477,7 +497,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t grp = blockIdx.x, ch = blockIdx.z;
   const uint32_t row0 = (uint32_t)grp * C::G;
-  const int g2 = tid % C::G, d2 = tid / C::G;
+  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;
   fill_step_twiddles<T, C>(tw);
   __syncthreads();
 
@@ -487,12 +507,12 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   T mx = T(0);
   double plogp = 0.0;
   // The linear kind works on the time residues t1 = r - 1, r = row0 + g (so r = 0 is t1 = -1, i.e. the samples
-  // N1 t2 - 1): the kept samples [n/2 - 1, 3n/2 - 1) are then exactly c in [8, 24) for every row and each run of
-  // G outputs starts on a 128-byte boundary of the panel.
+  // N1 t2 - 1): the kept samples [n/2 - 1, 3n/2 - 1) are then exactly t2 in [256, 768), i.e. c1 in [4, 12), for every
+  // row, and each run of G outputs starts on a 128-byte boundary of the panel.
   const uint32_t t1_first = row0 - (KIND == 0 ? 1u : 0u);
   // panel offset of this thread's first output and the stride between its outputs
-  const uint32_t tbase = row0 + g2 + (uint32_t)a.N1 * d2;
-  const uint32_t tstep = 32u * (uint32_t)a.N1;
+  const uint32_t tbase = row0 + g2 + (uint32_t)a.N1 * (d2 + 16 * c2);
+  const uint32_t tstep = 64u * (uint32_t)a.N1;
   const cplx<T>* Xc = a.X + ch * a.Lf;
   int64_t pending = -1;  // band whose row sum sits in s_red waiting for a barrier
   int par = 0;
@@ -506,7 +526,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
     const BandDesc bd = a.bands[jj];
     const int64_t j = bd.out_band;  // row of the panel this band writes
     QI_STAMP(7);
-    cplx<T> v[32], u[32];
+    cplx<T> v[16], u[16];
     auto flush = [&] {
       if (pending >= 0 && tid == 0) {
         double s = 0.0;
@@ -515,22 +535,22 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       }
     };
     if (bd.mode == 0) {
-      if (!QI_DBG(2)) load_pruned<T, C, STX>(buf, tw + C::NR, a, bd, Xc, t1_first);
+      if (!QI_DBG(2)) load_pruned<T, C, STX>(buf, tw + C::NR + C::TW2, a, bd, Xc, t1_first);
       __builtin_amdgcn_sched_barrier(0);
       QI_STAMP(0);
       __syncthreads();
       QI_STAMP(1);
 #pragma unroll
-      for (int b = 0; b < 32; ++b) v[b] = buf[(tid / 32) * C::SR + (tid % 32) + 32 * b];
+      for (int b = 0; b < 16; ++b) v[b] = buf[(tid / 64) * C::SR + (tid % 64) + 64 * b];
     } else {
       if (!QI_DBG(2))
-        load_imd_direct<T>(v, a.imd + ((int64_t)ch * a.imd_slots + bd.gen_slot) * a.Lf, row0 + tid / 32, tid % 32);
+        load_imd_direct<T>(v, a.imd + ((int64_t)ch * a.imd_slots + bd.gen_slot) * a.Lf, row0 + tid / 64, tid % 64);
       QI_STAMP(0);
     }
 #ifdef QI_NATIVE_STAMPS
-    rows_fft1024_regs<T, C>(v, buf, tw, u, QI_DBG(4), flush, st_acc, st_last);
+    rows_fft1024_regs<T, C>(v, buf, tw, u, QI_DBG(4), flush, [] {}, st_acc, st_last);
 #else
-    rows_fft1024_regs<T, C>(v, buf, tw, u, QI_DBG(4), flush);
+    rows_fft1024_regs<T, C>(v, buf, tw, u, QI_DBG(4), flush, [] {});
 #endif
 
     const int64_t orow = ((int64_t)ch * a.panel_bands + j) * a.n;
@@ -543,8 +563,8 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
     T rowacc = T(0), pl = T(0);
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      const int c = KIND == 0 ? i + 8 : (KIND == 1 ? ((i + 16) & 31) : i);
-      const cplx<T> z = u[brev(c, 5)];
+      const int c = KIND == 0 ? i + 4 : (KIND == 1 ? ((i + 8) & 15) : i);
+      const cplx<T> z = u[brev(c, 4)];
       const uint32_t tt = tb + (uint32_t)i * tstep;
       if (COEF && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
       const T m2 = z.x * z.x + z.y * z.y;
@@ -877,7 +897,7 @@ static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
 template <>
 int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
   if (a.ngen_launch <= 0) return QI_OK;
-  using C = Cfg<float, 16, false>;
+  using C = Cfg<float>;
   dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
   const bool stx = kind == 2;
   if (a.N1 == 1024) return stx ? launch_p1<float, C, 1, 1>(a, grid, st) : launch_p1<float, C, 0, 1>(a, grid, st);
@@ -889,8 +909,8 @@ int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, h
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
 template <>
 int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
-  using C1 = Cfg<float, 16, false>;
-  using C2 = Cfg<float, 16, false>;
+  using C1 = Cfg<float>;
+  using C2 = Cfg<float>;
   dim3 g1((unsigned)(a.N2 / C1::G), 1, (unsigned)n_channels);
   if (a.N1 == 1024)
     QI_TRY((launch_p1<float, C1, 2, 1>(a, g1, st)));
@@ -926,7 +946,7 @@ static int launch_pass2_cfg(const RowArgs<float>& a, int kind, int nchunk, int64
 template <>
 int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
                         hipStream_t st) {
-  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float, 16, false>>(a, kind, nchunk, n_channels, st);
+  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float>>(a, kind, nchunk, n_channels, st);
   // (an 8-row variant with two workgroups per CU was measured 20 % slower: shorter store runs, twice the per-band setup)
   set_error("pass 2 supports 16 rows per workgroup, got %d", rows_per_group);
   return QI_ERR_UNSUPPORTED;
