@@ -880,7 +880,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
-    if (v == 16) p->native_rows = (int)v;
+    if (v == 8 || v == 16) p->native_rows = (int)v;
   }
   p->ws_bytes = desc->workspace_bytes > 0 ? (size_t)desc->workspace_bytes : ((size_t)2 << 30);
   if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {

@@ -100,9 +100,9 @@ __device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double
 // four waves per SIMD).  The 1024-point row transform is 16 x 16 x 4: step 1, thread (row g, a) transforms
 // x[a + 64 b] over b; after the exchange through LDS, thread (d, c2, row g) -- wave = d, lanes = (c2, g) so that
 // stores run over the 16 rows -- folds the radix-4 over q (a = a1 + 16 q) for its own c2 and transforms over a1.
-template <typename T>
+template <typename T, int G_ = 16>
 struct Cfg {
-  static constexpr int NR = 1024, G = 16, TH = 1024;
+  static constexpr int NR = 1024, G = G_, TH = 64 * G_;
   static constexpr int SR = NR + 1;      // row stride of the natural-order image A[g][k]
   static constexpr int SA = 16 * G + 1;  // a-stride of the exchange image E[a][d][g]
   static constexpr int BUF = (G * SR > 64 * SA) ? G * SR : 64 * SA;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void rows_fft1024_regs(cplx<T> (&v)[16], cplx<T>* buf
 ) {
   const int tid = threadIdx.x;
   const int g1 = tid / 64, a1 = tid % 64;
-  const int d2 = tid / 64, lane = tid % 64, c2 = lane / 16, g2 = lane % 16;
+  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;
   if (!skip) {
     fft_reg<T, 16, 1>(v);
 #pragma unroll
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const int tid = threadIdx.x;
   const int64_t ch = blockIdx.z;
   const uint32_t row0 = blockIdx.x * C::G;
-  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;  // lanes run over the G rows: stores are runs of G k2
+  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;  // lanes run over the G rows
   fill_step_twiddles<T, C>(tw);
   BandDesc bd{};
   if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y]];
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(C::TH) k_fwd2(RowArgs<T> a, cplx<T>* __restric
   const int tid = threadIdx.x;
   const int64_t ch = blockIdx.z;
   const uint32_t row0 = blockIdx.x * C::G;
-  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;
+  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;
   fill_step_twiddles<T, C>(tw);
   cplx<T> v[16], u[16];
   load_imd_direct<T>(v, a.imd + (int64_t)ch * a.imd_slots * a.Lf, row0 + tid / 64, tid % 64);
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t grp = blockIdx.x, ch = blockIdx.z;
   const uint32_t row0 = (uint32_t)grp * C::G;
-  const int d2 = tid / 64, c2 = (tid % 64) / 16, g2 = tid % 16;
+  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;
   fill_step_twiddles<T, C>(tw);
   __syncthreads();
 
@@ -946,9 +946,10 @@ static int launch_pass2_cfg(const RowArgs<float>& a, int kind, int nchunk, int64
 template <>
 int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
                         hipStream_t st) {
-  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float>>(a, kind, nchunk, n_channels, st);
-  // (an 8-row variant with two workgroups per CU was measured 20 % slower: shorter store runs, twice the per-band setup)
-  set_error("pass 2 supports 16 rows per workgroup, got %d", rows_per_group);
+  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float, 16>>(a, kind, nchunk, n_channels, st);
+  // 8 rows: half the LDS image, two workgroups per CU that hide each other's barriers, but 64-byte store runs
+  if (rows_per_group == 8) return launch_pass2_cfg<Cfg<float, 8>>(a, kind, nchunk, n_channels, st);
+  set_error("pass 2 supports 8 or 16 rows per workgroup, got %d", rows_per_group);
   return QI_ERR_UNSUPPORTED;
 }
 
