@@ -495,6 +495,7 @@ int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B,
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
     d.out_band = ids[q];
     d.edge = edge_w.empty() ? 0 : edge_w[q];
+    d.edge_slot = (int32_t)q;  // the edge list is in the order of `ids`
     if (len > 0 && len <= p->native_kmax) {
       d.mode = 0;
       d.k_lo = (int32_t)lo;
@@ -601,10 +602,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const bool shorts = kind == 0 && p->nat[3].ready && p->nedge > 0;
   if (shorts) subs.push_back({&p->nat[3], 1, 0, 0, {}});
   const int64_t n = p->n, B = p->nat[kind].nbands, Lf0 = p->nat[kind].Lf;
-  if (shorts && !out->coef) {
-    set_error("native styx CWT: the coefficient panel is required (short-atom bands are corrected in place)");
-    return QI_ERR_UNSUPPORTED;
-  }
   const T* sig = static_cast<const T*>(sig_v);
   const int G = p->native_rows;
   int64_t nblk_max = 0, imd_elems = 0;
@@ -639,7 +636,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
   const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
-  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et;
+  const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
+  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez;
   if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
               per_chan + 4096);
@@ -663,6 +661,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   T* time_part = reinterpret_cast<T*>(carve(e_tp));
   T* edge_p = reinterpret_cast<T*>(carve(e_ep));
   T* edge_time = reinterpret_cast<T*>(carve(e_et));
+  cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
 
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
@@ -709,6 +708,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       a.neg_last_row = sb.kernel_kind == 0 ? 1 : 0;
       a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
       a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      a.edge_z = edge_z;
+      a.edge_wmax = p->edge_wmax;
+      a.nedge = p->nedge;
       a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
       a.part_band = want_band ? part_band : nullptr;
       a.part_stat = want_stat ? part_stat : nullptr;
@@ -744,7 +746,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       e.wmax = p->edge_wmax;
       e.stat_slots = stat_slots;
       e.sig = sig + c0 * n;
-      e.coef = static_cast<cplx<T>*>(out->coef) + c0 * B * n;
+      e.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      e.edge_z = edge_z;
       e.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
       e.edge_p = edge_p;
       e.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);

@@ -561,6 +561,14 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
     uint32_t tb = tbase;
     asm volatile("" : "+v"(tb));
     T rowacc = T(0), pl = T(0);
+    if (KIND == 1 && !COEF && bd.edge > 0 && a.edge_z) {
+      // no panel to correct in place: hand the circular values of the edge samples (panel positions i = 0 and 15,
+      // edge <= n / 16) to k_edge_fix through edge_z
+      cplx<T>* ez = a.edge_z + ((int64_t)ch * a.nedge + bd.edge_slot) * 2 * a.edge_wmax;
+      const uint32_t t_lo = tb, t_hi = (uint32_t)a.n - 1u - (tb + 15u * tstep);
+      if (t_lo < (uint32_t)bd.edge) ez[t_lo] = u[brev(8, 4)];
+      if (t_hi < (uint32_t)bd.edge) ez[a.edge_wmax + t_hi] = u[brev(7, 4)];
+    }
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       const int c = KIND == 0 ? i + 4 : (KIND == 1 ? ((i + 8) & 15) : i);
@@ -727,10 +735,10 @@ __global__ void __launch_bounds__(256) k_edge_fix(EdgeArgs<T> a) {
   si = wave_sum(si);
   if (lane == 0) {
     const int64_t row = (c * a.panel_bands + eb.out_band) * a.n;
-    cplx<T> z = a.coef[row + t];
+    cplx<T> z = a.coef ? a.coef[row + t] : a.edge_z[((c * a.nedge + e) * 2 + side) * a.wmax + tloc];
     z.x -= sr;
     z.y -= si;
-    a.coef[row + t] = z;
+    if (a.coef) a.coef[row + t] = z;
     const T m2 = z.x * z.x + z.y * z.y;
     if (a.bits) a.bits[row + t] = log2_t(sqrt_t(m2) + a.eps);
     a.edge_p[((c * a.nedge + e) * 2 + side) * a.wmax + tloc] = a.power_scale * m2;

@@ -16,7 +16,7 @@ struct BandDesc {
   int32_t out_band;  // row of the panel this band writes
   int32_t bank_row;  // general Gabor bands: row of the full-spectrum bank
   int32_t edge;      // circularly evaluated short-atom band: samples at each record end fixed by k_edge_fix
-  int32_t pad_;
+  int32_t edge_slot; // index of that band in the edge list (rows of RowArgs::edge_z)
   int64_t src_off;   // pruned Gabor bands: offset of H[k_lo] in the compact bank
   int64_t shift;     // Stockwell: shift index idx_j
   double coef;       // Stockwell: window coefficient (exp2(-(coef k)^2))
@@ -42,6 +42,9 @@ struct RowArgs {
   // pass 2 outputs
   cplx<T>* coef;
   T* bits;
+  cplx<T>* edge_z;    // [C][nedge][2][edge_wmax]: edge samples of the short-atom bands when no panel is stored
+  int64_t edge_wmax;
+  int32_t nedge;
   T* time_part;       // [C][chunk_total][n]
   double* part_band;  // [C][panel_bands][nblk]
   double* part_stat;  // [C][chunk_total][nblk][3]
@@ -70,7 +73,8 @@ struct EdgeArgs {
   int32_t nedge, panel_bands;
   int64_t n, wmax, stat_slots;
   const T* sig;       // [C][n]
-  cplx<T>* coef;      // panel
+  cplx<T>* coef;      // panel, or null: the edge samples are then in edge_z
+  cplx<T>* edge_z;    // [C][nedge][2][wmax]
   T* bits;            // optional
   T* edge_p;          // [C][nedge][2][wmax] corrected powers
   T power_scale, eps;

@@ -291,6 +291,11 @@ def test_native_engine_batches_match_single_records():
                 # the band-chunking (hence the summation order over bands) depends on the channel count
                 assert torch.allclose(one.power_time[0], batch.power_time[c], rtol=1e-5, atol=1e-7 * float(one.power_time.max()))
                 assert torch.allclose(one.stats[0], batch.stats[c], rtol=1e-5)
+            # reductions without a stored panel (the short-atom bands hand their edge samples over in scratch)
+            lean = getattr(plan, name)(x, coef=False, reductions=True)
+            assert lean.coef is None
+            assert torch.equal(lean.power_band, batch.power_band), (name, n)
+            assert torch.equal(lean.power_time, batch.power_time) and torch.equal(lean.stats, batch.stats)
             gold = getattr(ref, name)(x[1:2], coef=True, bits=(n == 1 << 19), reductions=True)
             scale = float(gold.coef.abs().max())
             assert float((gold.coef[0] - batch.coef[1]).abs().max()) / scale <= 2e-5, (name, n)
