@@ -114,6 +114,9 @@ int qi_gabor_atoms(int device, int64_t n, int32_t n_bands, const double* p_re, c
 int qi_plan_set_stx_bands(qi_plan* plan, int32_t n_bands, const int64_t* shift_index, const double* sigma);
 
 int64_t qi_plan_bands(const qi_plan* plan, int which /* qi_bank, or 2 for the STX table */);
+/* Bands of table `which` whose coefficients are produced by the kernels of profiling stage `stage` (qi_stage below:
+ * PASS2 or BLOCK on the native engine, INVERSE on the hipFFT engine); used to price a stage's algorithmic bytes. */
+int64_t qi_plan_stage_bands(const qi_plan* plan, int which, int stage);
 
 /* ---- measurement ------------------------------------------------------------------- */
 /* Stages of one transform call, timed with HIP events on the caller's stream when profiling is on
@@ -125,9 +128,14 @@ typedef enum {
   QI_STAGE_EPILOGUE = 3, /* crop / power / entropy epilogue (hipFFT engine)                      */
   QI_STAGE_PASS1 = 4,    /* native engine: fused multiply + first FFT pass                       */
   QI_STAGE_PASS2 = 5,    /* native engine: second FFT pass + fused epilogue                      */
-  QI_STAGE_COUNT = 6
+  QI_STAGE_BLOCK = 6,    /* native engine: short-atom bands by overlap-save blocks (forward, filter, inverse,  */
+                         /* epilogue in one kernel)                                                             */
+  QI_STAGE_COUNT = 7
 } qi_stage;
-int qi_plan_profile(qi_plan* plan, int enable); /* enabling or disabling also clears the counters */
+/* enable: 0 off, 1 every stage, otherwise a mask with bit (stage + 1) set for each stage to time (every recorded
+ * event is a small bubble in the stream, so a caller that wants one stage asks for that one).  Enabling or
+ * disabling also clears the counters. */
+int qi_plan_profile(qi_plan* plan, int enable);
 /* Sum of elapsed milliseconds and number of launches per stage since the last read; waits for the
  * recorded events.  Arrays of QI_STAGE_COUNT entries. */
 int qi_plan_profile_read(qi_plan* plan, double* stage_ms, int64_t* stage_launches, int32_t n_stages);

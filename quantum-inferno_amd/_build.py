@@ -13,10 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libqi_tfr.so")
-SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip"]
+SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip", "qi_block.hip"]
 ARCH = "gfx950"
 # the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950)
-PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",)}
+PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize",)}
 
 
 def torch_lib_dir():
@@ -68,6 +68,10 @@ if __name__ == "__main__":
     if "--stamps" in sys.argv:  # diagnostic library with in-kernel phase stamps (never the shipped one)
         print(build(force=True, extra_flags=("-DQI_NATIVE_STAMPS", "-DQI_NATIVE_DEBUG"),
                     lib=os.path.join(HERE, "libqi_tfr_stamps.so")))
+    elif "--variant" in sys.argv:  # experiment library: --variant NAME -DFLAG ... -> libqi_tfr_NAME.so
+        i = sys.argv.index("--variant")
+        print(build(force=True, extra_flags=tuple(sys.argv[i + 2:]),
+                    lib=os.path.join(HERE, f"libqi_tfr_{sys.argv[i + 1]}.so")))
     else:
         build(force="--force" in sys.argv)
         print(LIB)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("QI_TFR_LIB") or os.path.join(_HERE, "libqi_tfr.so")  
 QI_F32, QI_F64 = 0, 1
 QI_BANK_STYX, QI_BANK_ATOMS, QI_TABLE_STX = 0, 1, 2
 QI_ENGINE_AUTO, QI_ENGINE_HIPFFT, QI_ENGINE_NATIVE = 0, 1, 2
-STAGES = ("forward", "multiply", "inverse", "epilogue", "pass1", "pass2")
+STAGES = ("forward", "multiply", "inverse", "epilogue", "pass1", "pass2", "block")
 
 
 class QiError(RuntimeError):
@@ -57,6 +57,7 @@ PROTOTYPES = {
     "qi_gabor_atoms": (_int, [_int, _i64, _i32, _D, _D, _D, _D, _P, _P]),
     "qi_plan_set_stx_bands": (_int, [_P, _i32, _I64, _D]),
     "qi_plan_bands": (_i64, [_P, _int]),
+    "qi_plan_stage_bands": (_i64, [_P, _int, _int]),
     "qi_plan_profile": (_int, [_P, _int]),
     "qi_plan_profile_read": (_int, [_P, _D, _I64, _i32]),
     "qi_cwt": (_int, [_P, _int, _P, _i64, C.POINTER(TfrOut), _P]),

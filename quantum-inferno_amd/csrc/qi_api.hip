@@ -1,4 +1,5 @@
 // C ABI of libqi_tfr.so: plans, tiling over (channel, band) tiles, the hipFFT engine.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -120,39 +121,50 @@ int fft_r2c<double>(FftCache& fc, double* in, double2* out, int64_t len, int64_t
 
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 struct Profiler {
-  static constexpr int kStages = 6;
+  static constexpr int kStages = QI_STAGE_COUNT;
   bool on = false;
+  uint32_t mask = ~0u;  // stages that are timed (bit = stage)
   struct Span {
-    hipEvent_t a, b;
+    int a, b;  // indices into `used`
     int stage;
   };
   std::vector<Span> spans;
+  std::vector<hipEvent_t> used;  // events recorded since the last read
   std::vector<hipEvent_t> pool;
-  hipEvent_t cur = nullptr;
+  int cur = -1;
+  int last = -1;  // the event that closed the previous span, while nothing has been launched since: the next
+                  // span starts on it instead of recording another one (every record is a bubble in the stream)
 
-  hipEvent_t get() {
-    if (!pool.empty()) {
-      hipEvent_t e = pool.back();
-      pool.pop_back();
-      return e;
-    }
+  int record(hipStream_t st) {
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
+    if (!pool.empty()) {
+      e = pool.back();
+      pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      return -1;
+    }
+    (void)hipEventRecord(e, st);
+    used.push_back(e);
+    return (int)used.size() - 1;
   }
-  void begin(hipStream_t st) {
-    if (!on) return;
-    cur = get();
-    if (cur) (void)hipEventRecord(cur, st);
+  void unchain() { last = -1; }
+  void begin(hipStream_t st, int stage) {
+    cur = -1;
+    if (!on || !((mask >> stage) & 1u)) {
+      last = -1;
+      return;
+    }
+    cur = last >= 0 ? last : record(st);
   }
   void end(int stage, hipStream_t st) {
-    if (!on || !cur) return;
-    hipEvent_t b = get();
-    if (b) {
-      (void)hipEventRecord(b, st);
+    last = -1;
+    if (!on || cur < 0) return;
+    const int b = record(st);
+    if (b >= 0) {
       spans.push_back({cur, b, stage});
+      last = b;
     }
-    cur = nullptr;
+    cur = -1;
   }
   void read(double* ms, int64_t* count) {
     for (int i = 0; i < kStages; ++i) {
@@ -161,14 +173,15 @@ struct Profiler {
     }
     for (auto& s : spans) {
       float t = 0.f;
-      if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+      if (hipEventSynchronize(used[s.b]) == hipSuccess && hipEventElapsedTime(&t, used[s.a], used[s.b]) == hipSuccess) {
         ms[s.stage] += t;
         count[s.stage] += 1;
       }
-      pool.push_back(s.a);
-      pool.push_back(s.b);
     }
+    for (auto e : used) pool.push_back(e);
+    used.clear();
     spans.clear();
+    cur = last = -1;
   }
   void clear() {
     double ms[kStages];
@@ -221,6 +234,26 @@ struct qi_plan {
       *this = NativeTable();
     }
   } nat[4];  // 0 styx bank (linear, Lf = 2n), 1 atoms bank (circular), 2 Stockwell, 3 styx short-atom bands (circular n)
+  // block engine (qi_block.hip): bands whose atoms reach at most 1024 samples, per transform kind, in three
+  // groups by reach (256, 512, 1024 samples)
+  struct BlockTable {
+    bool ready = false;
+    int demod = 0;
+    void* bank = nullptr;  // [rows][kBlk] complex filter spectra
+    int32_t rows = 0;
+    native::BlockBand* d_bands = nullptr;  // all reach groups, group by group
+    native::BlockItem* d_items = nullptr;  // one per workgroup, most expensive first
+    int32_t nitems = 0, nplanes = 0;
+    int64_t max_blocks = 0;  // partial slots a band row needs
+    void release() {
+      if (bank) (void)hipFree(bank);
+      if (d_bands) (void)hipFree(d_bands);
+      if (d_items) (void)hipFree(d_items);
+      *this = BlockTable();
+    }
+  } blk[3];
+  int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
+  int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
   int64_t edge_wmax = 0;
@@ -318,23 +351,23 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
 
   for (int64_t c0 = 0; c0 < C; c0 += tl.Ct) {
     const int64_t ct = (C - c0 < tl.Ct) ? C - c0 : tl.Ct;
-    p->prof.begin(st);
+    p->prof.begin(st, QI_STAGE_FORWARD);
     QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, L, st));
     QI_TRY(fft_c2c<T>(p->fft, X, L, ct, HIPFFT_FORWARD, st));
     p->prof.end(QI_STAGE_FORWARD, st);
     int64_t tb = 0;
     for (int64_t j0 = 0; j0 < B; j0 += tl.Bt, ++tb) {
       const int64_t bt = (B - j0 < tl.Bt) ? B - j0 : tl.Bt;
-      p->prof.begin(st);
+      p->prof.begin(st, QI_STAGE_MULTIPLY);
       if (kind == Kind::Stockwell)
         QI_TRY(launch_stx_window<T>(X, Y, ct, bt, n, p->d_stx_idx + j0, p->d_stx_coef + j0, st));
       else
         QI_TRY(launch_mul_bank<T>(X, H + j0 * L, Y, ct, bt, L, st));
       p->prof.end(QI_STAGE_MULTIPLY, st);
-      p->prof.begin(st);
+      p->prof.begin(st, QI_STAGE_INVERSE);
       QI_TRY(fft_c2c<T>(p->fft, Y, L, ct * bt, HIPFFT_BACKWARD, st));
       p->prof.end(QI_STAGE_INVERSE, st);
-      p->prof.begin(st);
+      p->prof.begin(st, QI_STAGE_EPILOGUE);
       EpiArgs<T> a{};
       a.Y = Y;
       a.L = L;
@@ -361,6 +394,7 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, tl.nblk,
                              tl.ntb * tl.nblk, st));
+    p->prof.unchain();
   }
   return QI_OK;
 }
@@ -379,6 +413,11 @@ bool native_wanted(const qi_plan* p, int kind) {
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
 int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
+  if (bands.empty()) {  // every band is produced by the block engine: an empty but valid table
+    t.Lf = Lf;
+    t.ready = true;
+    return QI_OK;
+  }
   std::vector<int32_t> wide, narrow;
   for (size_t j = 0; j < bands.size(); ++j) (bands[j].mode == 1 ? wide : narrow).push_back((int32_t)j);
   const int32_t per = p->native_group > 0 ? p->native_group : (int32_t)wide.size();
@@ -480,6 +519,146 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
   return QI_OK;
 }
 
+// ---- block engine tables ------------------------------------------------------------------------------------------
+struct BlockPick {
+  int32_t band;   // panel row
+  int wq;         // reach group: taps within 256 * wq samples (1, 2 or 4)
+  int64_t shift;  // Stockwell shift index (0 for Gabor banks)
+};
+int block_group_of(double reach) { return reach <= 256.0 ? 1 : (reach <= 512.0 ? 2 : (reach <= 1024.0 ? 4 : 0)); }
+
+// `taps` holds one 4096-sample circular-convolution kernel per pick (float64, on the device, same order):
+// transform them, convert to the engine's precision and upload the per-group band lists.
+template <typename T>
+int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockPick>& picks, double2* taps,
+                       hipStream_t st) {
+  auto& bt = p->blk[kind];
+  bt.release();
+  if (picks.empty()) return QI_OK;
+  const int32_t rows = (int32_t)picks.size();
+  QI_TRY(fft_c2c<double>(p->fft, taps, native::kBlk, rows, HIPFFT_FORWARD, st));
+  QI_HIP(hipMalloc(&bt.bank, (size_t)rows * native::kBlk * sizeof(cplx<T>)));
+  QI_TRY(launch_bank_convert<T>(taps, static_cast<cplx<T>*>(bt.bank), (int64_t)rows * native::kBlk, 0,
+                                1.0 / (double)native::kBlk, st));
+  bt.rows = rows;
+  bt.demod = demod;
+  const int wqs[3] = {1, 2, 4};
+  std::vector<native::BlockBand> list;
+  std::vector<native::BlockItem> items;
+  for (int g = 0; g < 3; ++g) {
+    const int32_t first = (int32_t)list.size();
+    for (int32_t r = 0; r < rows; ++r) {
+      if (picks[r].wq != wqs[g]) continue;
+      native::BlockBand b;
+      memset(&b, 0, sizeof(b));
+      b.out_band = picks[r].band;
+      b.bank_row = r;
+      b.shift = (int32_t)picks[r].shift;
+      for (int k = 0; k < 4; ++k) {
+        // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
+        const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
+        const double ang = -2.0 * M_PI * (double)m / (double)p->n;
+        b.rot[2 * k] = (float)std::cos(ang);
+        b.rot[2 * k + 1] = (float)std::sin(ang);
+      }
+      list.push_back(b);
+    }
+    const int32_t count = (int32_t)list.size() - first;
+    if (count == 0) continue;
+    // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
+    const int32_t nchunk = (int32_t)ceil_div(count, p->native_blk_bands);
+    const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
+    if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
+    for (int32_t c = 0; c < nchunk; ++c) {
+      const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
+      const int32_t hi = first + (int32_t)((int64_t)count * (c + 1) / nchunk);
+      for (int64_t b = 0; b < nblocks; ++b) {
+        native::BlockItem it;
+        it.wq = wqs[g];
+        it.block = (int32_t)b;
+        it.band_first = lo;
+        it.band_count = hi - lo;
+        it.plane = bt.nplanes;
+        it.stat_slot = 0;
+        items.push_back(it);
+      }
+      bt.nplanes += 1;
+    }
+  }
+  std::stable_sort(items.begin(), items.end(),
+                   [](const native::BlockItem& x, const native::BlockItem& y) { return x.band_count > y.band_count; });
+  for (size_t i = 0; i < items.size(); ++i) items[i].stat_slot = (int32_t)i;
+  bt.nitems = (int32_t)items.size();
+  QI_HIP(hipMalloc((void**)&bt.d_bands, list.size() * sizeof(native::BlockBand)));
+  QI_HIP(hipMemcpy(bt.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
+  QI_HIP(hipMalloc((void**)&bt.d_items, items.size() * sizeof(native::BlockItem)));
+  QI_HIP(hipMemcpy(bt.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
+  QI_HIP(hipStreamSynchronize(st));
+  bt.ready = true;
+  return QI_OK;
+}
+
+// Gabor bands (styx bank): taps straight from the atom parameters.
+template <typename T>
+int build_block_gabor(qi_plan* p, int kind, int32_t B, const std::vector<BlockPick>& picks, const double* d_par,
+                      hipStream_t st) {
+  if (picks.empty()) {
+    p->blk[kind].release();
+    return QI_OK;
+  }
+  double2* taps = reinterpret_cast<double2*>(p->ws);
+  if (p->ws_bytes < picks.size() * native::kBlk * sizeof(double2)) {
+    set_error("workspace too small for the block-engine taps");
+    return QI_ERR_NOMEM;
+  }
+  const int wqs[3] = {1, 2, 4};
+  int32_t* d_ids = nullptr;
+  QI_HIP(hipMalloc((void**)&d_ids, picks.size() * sizeof(int32_t)));
+  int rc = QI_OK;
+  size_t r = 0;
+  // picks are ordered by group, so each group is one run of rows
+  for (int g = 0; g < 3 && rc == QI_OK; ++g) {
+    std::vector<int32_t> ids;
+    for (const auto& pk : picks)
+      if (pk.wq == wqs[g]) ids.push_back(pk.band);
+    if (ids.empty()) continue;
+    if (hipMemcpy(d_ids + r, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("hipMemcpy of block band ids failed");
+      rc = QI_ERR_HIP;
+      break;
+    }
+    rc = native::launch_block_taps_gabor(taps + r * native::kBlk, 256 * wqs[g], d_par, B, d_ids + r, (int)ids.size(), st);
+    r += ids.size();
+  }
+  if (rc == QI_OK) rc = finish_block_table<T>(p, kind, 0, picks, taps, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(d_ids);
+  return rc;
+}
+
+// Stockwell bands: the time-domain kernel is the inverse transform of the band's Gaussian window, computed as the
+// reference defines it (on the n signed FFT bins) and modulated to the band's shift index.
+template <typename T>
+int build_block_stx(qi_plan* p, const std::vector<BlockPick>& picks, const std::vector<double>& coef, hipStream_t st) {
+  if (picks.empty()) {
+    p->blk[2].release();
+    return QI_OK;
+  }
+  const size_t need = ((size_t)p->n + picks.size() * native::kBlk) * sizeof(double2);
+  if (p->ws_bytes < need) {
+    set_error("workspace too small for the block-engine taps (%zu bytes needed)", need);
+    return QI_ERR_NOMEM;
+  }
+  double2* row = reinterpret_cast<double2*>(p->ws);
+  double2* taps = row + p->n;
+  for (size_t r = 0; r < picks.size(); ++r) {
+    QI_TRY(native::launch_stx_window_row(row, p->n, coef[picks[r].band], st));
+    QI_TRY(fft_c2c<double>(p->fft, row, p->n, 1, HIPFFT_BACKWARD, st));
+    QI_TRY(native::launch_block_taps_stx(taps + r * native::kBlk, 256 * picks[r].wq, row, p->n, picks[r].shift, st));
+  }
+  return finish_block_table<T>(p, 2, 1, picks, taps, st);
+}
+
 // Classify bands by spectrum support, allocate and fill one table.
 template <typename T>
 int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B, const std::vector<int32_t>& ids,
@@ -509,7 +688,11 @@ int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B,
   }
   auto& t = p->nat[table];
   t.release();
-  if (ids.empty()) return QI_OK;
+  if (ids.empty()) {  // every band is produced elsewhere (block engine): an empty but valid table
+    t.Lf = L;
+    t.ready = table != 3;
+    return QI_OK;
+  }
   if (compact > 0) QI_HIP(hipMalloc(&t.Hc, (size_t)compact * sizeof(cplx<T>)));
   if (ngen > 0) QI_HIP(hipMalloc(&t.Hfull, (size_t)ngen * L * sizeof(cplx<T>)));
   QI_TRY(fill_native_bank<T>(p, t, circular, L, B, ids, bands, d_par, st));
@@ -529,13 +712,17 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
   std::vector<double> sup;
   QI_TRY(analyse_support(p, circular, L, B, 0, B, d_par, &sup, st));
   std::vector<int32_t> keep, shorts, short_w;
+  std::vector<BlockPick> picks;
   const bool can_short = !circular && p->native_short && native_len_ok(n) && is_pow2(n);
+  const bool can_block = !circular && p->native_block && is_pow2(n) && n >= 4 * native::kBlk;
   for (int32_t j = 0; j < B; ++j) {
     const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
     // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30
     const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
-    if (can_short && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 && w < (double)n / 8) {
+    if (can_block && block_group_of(w) > 0) {
+      picks.push_back({j, block_group_of(w), 0});
+    } else if (can_short && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 && w < (double)n / 8) {
       shorts.push_back(j);
       short_w.push_back((int32_t)w);
     } else {
@@ -545,7 +732,11 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
   std::vector<double> sup_keep;
   for (int32_t j : keep) sup_keep.insert(sup_keep.end(), sup.begin() + 3 * j, sup.begin() + 3 * j + 3);
   QI_TRY(make_native_table<T>(p, bank, circular, L, B, keep, sup_keep, {}, d_par, st));
-  p->nat[bank].nbands = B;  // the table's panel has all B rows even when some are produced by table 3
+  p->nat[bank].nbands = B;  // the table's panel has all B rows even when some are produced by table 3 / the block engine
+  if (bank == QI_BANK_STYX) {
+    std::stable_sort(picks.begin(), picks.end(), [](const BlockPick& x, const BlockPick& y) { return x.wq < y.wq; });
+    QI_TRY(build_block_gabor<T>(p, 0, B, picks, d_par, st));
+  }
   if (bank == QI_BANK_STYX) {
     p->nat[3].release();
     if (p->d_edge) (void)hipFree(p->d_edge);
@@ -621,12 +812,23 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     }
   }
   if (imd_elems < Lf0) imd_elems = Lf0;  // the forward transform of the records stages through one slot
-  const int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
-  const int64_t stat_slots = (int64_t)chunk_total * nbk + (shorts ? p->nedge : 0);
+  // block engine launches (one per reach group): their chunks come after the pass-2 chunks
+  const auto& bt = p->blk[kind];
+  const bool blocks = kind != 1 && bt.ready;
+  const int chunk_p2 = chunk_total;
+  int64_t blk_stats = 0, blk_slots = 0;
+  if (blocks) {
+    chunk_total += bt.nplanes;
+    blk_stats = bt.nitems;
+    blk_slots = bt.max_blocks;
+  }
+  int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
+  if (blk_slots > nbk) nbk = blk_slots;
+  const int64_t stat_slots = (int64_t)chunk_p2 * nbk + blk_stats + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
-  const bool clear_parts = subs.size() > 1;
+  const bool clear_parts = subs.size() > 1 || blocks;
   // scratch regions, each [Ct][...] without per-channel padding
   const size_t e_x = (size_t)Lf0 * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
@@ -665,7 +867,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
 
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
-    p->prof.begin(st);
+    p->prof.begin(st, QI_STAGE_FORWARD);
     if (p->native_fwd) {
       native::RowArgs<T> f{};
       f.Lf = Lf0;
@@ -726,17 +928,43 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         a.ngen_launch = grp.ngen;
         a.chunk_base = chunk_base;
         if (grp.ngen > 0) {
-          p->prof.begin(st);
+          p->prof.begin(st, QI_STAGE_PASS1);
           QI_TRY(native::launch_pass1<T>(a, sb.kernel_kind, ct, st));
           p->prof.end(QI_STAGE_PASS1, st);
         }
-        p->prof.begin(st);
+        p->prof.begin(st, QI_STAGE_PASS2);
         QI_TRY(native::launch_pass2<T>(a, sb.kernel_kind, G, sb.nchunk[g], ct, st));
         p->prof.end(QI_STAGE_PASS2, st);
         chunk_base += sb.nchunk[g];
       }
     }
-    p->prof.begin(st);
+    if (blocks) {
+      native::BlockArgs<T> b{};
+      b.n = n;
+      b.nitems = bt.nitems;
+      b.panel_bands = (int32_t)B;
+      b.items = bt.d_items;
+      b.bands = bt.d_bands;
+      b.bank = static_cast<const cplx<T>*>(bt.bank);
+      b.sig = sig + c0 * n;
+      b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      b.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      b.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+      b.part_band = want_band ? part_band : nullptr;
+      b.part_stat = want_stat ? part_stat : nullptr;
+      b.nblk = nbk;
+      b.stat_stride = stat_slots;
+      b.stat_base = (int64_t)chunk_p2 * nbk;
+      b.chunk_base = chunk_p2;
+      b.chunk_total = chunk_total;
+      b.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      b.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      b.two_over_n = (float)(2.0 / (double)n);
+      p->prof.begin(st, QI_STAGE_BLOCK);
+      QI_TRY(native::launch_block<T>(b, bt.demod, ct, st));
+      p->prof.end(QI_STAGE_BLOCK, st);
+    }
+    p->prof.begin(st, QI_STAGE_EPILOGUE);
     if (shorts) {
       native::EdgeArgs<T> e{};
       e.bands = p->d_edge;
@@ -881,6 +1109,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   }
 #endif
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -922,6 +1152,7 @@ int qi_plan_destroy(qi_plan* p) {
   }
 #endif
   for (auto& t : p->nat) t.release();
+  for (auto& t : p->blk) t.release();
   if (p->d_edge) (void)hipFree(p->d_edge);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
@@ -956,6 +1187,7 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     QI_HIP(hipMalloc(&p->bank[bank], (size_t)B * L * esz));
   }
   p->nat[bank].release();
+  if (bank == QI_BANK_STYX) p->blk[0].release();
   double* d_par = nullptr;
   QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
   std::vector<double> host((size_t)4 * B);
@@ -1035,13 +1267,24 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
   QI_HIP(hipMemcpy(p->d_stx_coef, coef.data(), B * sizeof(double), hipMemcpyHostToDevice));
   p->nb_stx = B;
   p->nat[2].release();
+  p->blk[2].release();
   if (native_wanted(p, 2)) {
     // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef
-    std::vector<native::BandDesc> bands(B);
+    std::vector<native::BandDesc> bands;
+    std::vector<BlockPick> picks;
+    const bool can_block = p->native_block && p->n >= 4 * native::kBlk;
     int32_t ngen = 0;
     (void)ngen;
     for (int32_t j = 0; j < B; ++j) {
-      native::BandDesc& d = bands[j];
+      // the band's time-domain kernel is a Gaussian of standard deviation sigma_j samples (above 2^-30 of its peak
+      // within sqrt(60 ln 2) sigma); it is only that short if the frequency window has decayed before Nyquist
+      const double reach = std::ceil(std::sqrt(60.0 * M_LN2) * sigma[j]) + 1.0;
+      if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0) {
+        picks.push_back({j, block_group_of(reach), shift_index[j]});
+        continue;
+      }
+      bands.emplace_back();
+      native::BandDesc& d = bands.back();
       memset(&d, 0, sizeof(d));
       d.shift = shift_index[j];
       d.coef = coef[j];
@@ -1057,6 +1300,8 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       }
     }
     QI_TRY(upload_native_table(p, 2, p->n, bands));
+    p->nat[2].nbands = B;
+    QI_TRY(build_block_stx<float>(p, picks, coef, nullptr));
   } else if (p->d.engine == QI_ENGINE_NATIVE) {
     set_error("native engine does not support the Stockwell transform at n = %lld", (long long)p->n);
     return QI_ERR_UNSUPPORTED;
@@ -1070,6 +1315,16 @@ int64_t qi_plan_bands(const qi_plan* p, int which) {
   return which == 2 ? p->nb_stx : 0;
 }
 
+int64_t qi_plan_stage_bands(const qi_plan* p, int which, int stage) {
+  if (!p || which < 0 || which > 2) return 0;
+  const int64_t total = qi_plan_bands(p, which);
+  if (!p->nat[which].ready) return stage == QI_STAGE_INVERSE ? total : 0;
+  int64_t blk = 0;
+  if (which != 1 && p->blk[which].ready) blk = p->blk[which].rows;
+  if (stage == QI_STAGE_BLOCK) return blk;
+  return stage == QI_STAGE_PASS2 ? total - blk : 0;
+}
+
 int qi_plan_profile(qi_plan* p, int enable) {
   QI_REQUIRE(p, "null plan");
   DeviceGuard g(p->d.device);
@@ -1077,6 +1332,7 @@ int qi_plan_profile(qi_plan* p, int enable) {
   int64_t c[Profiler::kStages];
   p->prof.read(ms, c);
   p->prof.on = enable != 0;
+  p->prof.mask = enable == 1 ? ~0u : (uint32_t)enable >> 1;
   return QI_OK;
 }
 
@@ -1094,6 +1350,7 @@ int qi_cwt(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* o
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
   const Kind k = bank == QI_BANK_STYX ? Kind::Linear : Kind::Circular;
+  p->prof.unchain();
   if (p->nat[bank].ready) return run_native<float>(p, bank, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, k, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, k, sig, C, out, (hipStream_t)stream);
@@ -1103,6 +1360,7 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
   QI_REQUIRE(p && sig && out, "null argument");
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
+  p->prof.unchain();
   if (p->nat[2].ready) return run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);

@@ -1,0 +1,374 @@
+// Block engine: the wide-spectrum bands of a panel have SHORT atoms in time (a few tens to a thousand taps), so
+// they are evaluated as a short-time filter by overlap-save with 4096-point transforms that never leave the CU.
+//
+// One workgroup (256 threads, 16 values per thread) owns kBlk = 4096 consecutive record samples starting W before
+// its first output: it transforms them once (forward, kept in registers) and then, for every band of its list,
+// multiplies by the band's 4096-point filter spectrum (a [bands][4096] table that stays in L2), transforms back
+// through LDS and keeps the V = 4096 - 2 W outputs that no wrapped tap touched.  Outputs of a thread are the
+// samples a + 256 c: every store is a 512-byte run of the panel.  The zero padding of the reference's linear
+// correlation (styx_cwt.py:147-198) is the zero extension of the block loads at the record ends; the circular
+// Stockwell transform (styx_stx.py:195-236) wraps the loads instead and multiplies the outputs by the
+// demodulation phasor exp(-2 pi i idx t / n).  No intermediate in HBM, no pass 1, no edge correction.
+//
+// 4096 = 16 x 16 x 16 (decimation in frequency): k = k0 + 16 k1 + 256 k2, q = 256 q0 + 16 q1 + q2,
+//   y[q] = sum_k0 W16^(k0 q0) W256^(k0 q1) sum_k1 W16^(k1 q1) W4096^((k0 + 16 k1) q2) sum_k2 W16^(k2 q2) Y[k].
+// Thread a = k0 + 16 k1 holds Y[a + 256 k2] on entry and y[a + 256 q0] on exit, so forward and inverse chain
+// without a reordering.  No MFMA: there is no dense contraction here.
+#include "qi_common.hpp"
+#include "qi_device.hpp"
+#include "qi_native.hpp"
+#include "qi_fft_reg.hpp"
+
+namespace qi {
+namespace native {
+
+namespace {
+
+constexpr int kBlkThreads = 256;
+#ifndef QI_BLK_WAVES
+#define QI_BLK_WAVES 3  // waves per SIMD the block kernel is compiled for (register budget 512 / QI_BLK_WAVES)
+#endif
+constexpr int kBlkPad = 257;  // k0-stride of the second exchange image (conflict-free transposed reads)
+
+template <typename T>
+__device__ __forceinline__ cplx<T> cconj(cplx<T> v) {
+  return mk<T>(v.x, -v.y);
+}
+
+// v[brev(q)] *= w^q, q = 1..15, powers by products of w, w^2, w^4, w^8 (depth <= 4 roundings)
+template <typename T>
+__device__ __forceinline__ void mul_powers16(cplx<T> (&v)[16], cplx<T> w) {
+  const cplx<T> p1 = w, p2 = cmul(p1, p1), p4 = cmul(p2, p2), p8 = cmul(p4, p4);
+  const cplx<T> p3 = cmul(p2, p1), p5 = cmul(p4, p1), p6 = cmul(p4, p2), p7 = cmul(p4, p3);
+  v[brev(1, 4)] = cmul(v[brev(1, 4)], p1);
+  v[brev(2, 4)] = cmul(v[brev(2, 4)], p2);
+  v[brev(3, 4)] = cmul(v[brev(3, 4)], p3);
+  v[brev(4, 4)] = cmul(v[brev(4, 4)], p4);
+  v[brev(5, 4)] = cmul(v[brev(5, 4)], p5);
+  v[brev(6, 4)] = cmul(v[brev(6, 4)], p6);
+  v[brev(7, 4)] = cmul(v[brev(7, 4)], p7);
+  v[brev(8, 4)] = cmul(v[brev(8, 4)], p8);
+  v[brev(9, 4)] = cmul(v[brev(9, 4)], cmul(p8, p1));
+  v[brev(10, 4)] = cmul(v[brev(10, 4)], cmul(p8, p2));
+  v[brev(11, 4)] = cmul(v[brev(11, 4)], cmul(p8, p3));
+  v[brev(12, 4)] = cmul(v[brev(12, 4)], cmul(p8, p4));
+  v[brev(13, 4)] = cmul(v[brev(13, 4)], cmul(p8, p5));
+  v[brev(14, 4)] = cmul(v[brev(14, 4)], cmul(p8, p6));
+  v[brev(15, 4)] = cmul(v[brev(15, 4)], cmul(p8, p7));
+}
+
+// 4096-point transform of the workgroup's block.  Entry: v[b] = in[tid + 256 b]; exit: v[brev(c)] = out[tid + 256 c].
+// `w` = W4096^tid (inverse sign), `tw256[m]` = W256^m (inverse sign); DIR = -1 conjugates both.
+template <typename T, int DIR>
+__device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
+                                        cplx<T> w, int tid) {
+  fft_reg<T, 16, DIR>(v);  // over k2 -> q2
+  // the powers of w do not depend on the band: hide that from the optimiser, which would otherwise keep all fifteen
+  // in registers across the band loop
+  asm volatile("" : "+v"(w.x), "+v"(w.y));
+  mul_powers16<T>(v, DIR > 0 ? w : cconj<T>(w));
+  __syncthreads();  // the previous transform's readers are done with buf
+  {
+    cplx<T> t[16];
+#pragma unroll
+    for (int q2 = 0; q2 < 16; ++q2) t[q2] = v[brev(q2, 4)];
+#pragma unroll
+    for (int q2 = 0; q2 < 16; ++q2) buf[q2 * 256 + tid] = t[q2];
+  }
+  __syncthreads();
+  const int k0 = tid & 15, q2t = tid >> 4;
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = buf[q2t * 256 + 16 * k1 + k0];
+  fft_reg<T, 16, DIR>(v);  // over k1 -> q1
+#pragma unroll
+  for (int q1 = 1; q1 < 16; ++q1) {
+    const cplx<T> t = tw256[(k0 * q1) & 255];
+    v[brev(q1, 4)] = cmul(v[brev(q1, 4)], DIR > 0 ? t : cconj<T>(t));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q1 = 0; q1 < 16; ++q1) buf[k0 * kBlkPad + q1 * 16 + q2t] = v[brev(q1, 4)];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = buf[k * kBlkPad + tid];
+  fft_reg<T, 16, DIR>(v);  // over k0 -> q0
+}
+
+// One work item: block `it.block` of the reach group WQ (taps within W = 256 WQ samples), bands
+// [it.band_first, it.band_first + it.band_count) of the launch's list.  DEMOD: Stockwell (circular loads, demodulated
+// outputs).
+template <typename T, int WQ, bool DEMOD, bool COEF, bool BITS>
+__device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
+                                           const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
+                                           cplx<T> w) {
+  constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int64_t blk = it.block, ch = blockIdx.z;
+  const int64_t n = a.n;
+  // record samples [t0, t0 + 4096), outputs [t0 + W, t0 + W + V)
+  const int64_t t0 = blk * V - W;
+  cplx<T> S[16];
+  {
+    const T* __restrict__ sig = a.sig + ch * n;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      int64_t t = t0 + tid + 256 * b;
+      T x;
+      if (DEMOD) {
+        t = (t + n) & (n - 1);  // circular (n is a power of two, t >= -n)
+        x = sig[t];
+      } else {
+        x = (t >= 0 && t < n) ? sig[t] : T(0);
+      }
+      S[b] = mk<T>(x, T(0));
+    }
+    fft4096<T, -1>(S, buf, tw256, w, tid);
+    cplx<T> t[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) S[c] = t[c];
+  }
+
+  T col[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) col[i] = T(0);
+  T mx = T(0);
+  double plogp = 0.0;
+  const uint32_t tb0 = (uint32_t)(t0 + W + tid);  // this thread's first output sample
+  int pending = -1, par = 0;  // band whose wave sums sit in s_red[par ^ 1] until a barrier has passed
+
+  for (int jj = 0; jj < it.band_count; ++jj) {
+    const BlockBand bd = a.bands[it.band_first + jj];
+    cplx<T> v[16];
+    {
+      const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + tid;
+      cplx<T> h[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) h[b] = H[256 * b];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
+    }
+    fft4096<T, 1>(v, buf, tw256, w, tid);
+    if (pending >= 0 && tid == 0) {
+      double r = 0.0;
+      for (int q = 0; q < NW; ++q) r += s_red[par ^ 1][q];
+      a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + blk] = r;
+    }
+
+    cplx<T> ph = mk<T>(T(1), T(0));
+    if (DEMOD) {
+      // exp(-2 pi i idx t / n) at this thread's first output; idx * t mod n is exact in 32-bit wraparound
+      const uint32_t m = (0u - (uint32_t)bd.shift * tb0) & (uint32_t)(n - 1);
+      float s, c;
+      sincospif((float)m * a.two_over_n, &s, &c);
+      ph = mk<T>((T)c, (T)s);
+    }
+    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
+    char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+    char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    uint32_t tb = tb0;
+    asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
+    T rowacc = T(0), pl = T(0);
+    cplx<T> rot[NOUT];  // demodulation phasor of output i: ph * r^i by binary powers r, r^2, r^4, r^8
+    if (DEMOD) {
+      rot[0] = ph;
+#pragma unroll
+      for (int i = 1; i < NOUT; ++i) {
+        const int low = i & -i;
+        const int k = low == 1 ? 0 : (low == 2 ? 1 : (low == 4 ? 2 : 3));
+        rot[i] = cmul_rn(rot[i - low], mk<T>((T)bd.rot[2 * k], (T)bd.rot[2 * k + 1]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int c = i + WQ;
+      cplx<T> z = v[brev(c, 4)];
+      if (DEMOD) z = cmul_rn(z, rot[i]);
+      const uint32_t tt = tb + 256u * (uint32_t)i;
+      const bool inside = tt < (uint32_t)n;
+      if (COEF && inside) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+      const T m2 = norm2(z.x, z.y);
+      if (BITS && inside) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
+      const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
+      col[i] += p;
+      rowacc += p;
+      mx = p > mx ? p : mx;
+      pl += plog2p(p);
+    }
+    plogp += (double)pl;
+    if (a.part_band) {
+      const double r = wave_sum((double)rowacc);
+      if (lane == 0) s_red[par][wv] = r;
+      pending = bd.out_band;
+      par ^= 1;
+    }
+  }
+
+  T tot = T(0);
+  char* __restrict__ time_row = reinterpret_cast<char*>(
+      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + it.plane) * n : nullptr);
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    tot += col[i];
+    const uint32_t tt = tb0 + 256u * (uint32_t)i;
+    if (time_row && tt < (uint32_t)n) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = col[i];
+  }
+  const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
+  __syncthreads();  // the last band's wave sums are visible; buf is free
+  if (pending >= 0 && tid == 0) {
+    double r = 0.0;
+    for (int q = 0; q < NW; ++q) r += s_red[par ^ 1][q];
+    a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + blk] = r;
+  }
+  if (a.part_stat) {
+    double* fin = reinterpret_cast<double*>(buf);
+    if (lane == 0) {
+      fin[wv] = r0;
+      fin[NW + wv] = r1;
+      fin[2 * NW + wv] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < NW; ++q) {
+        m = fin[q] > m ? fin[q] : m;
+        s1 += fin[NW + q];
+        s2 += fin[2 * NW + q];
+      }
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + it.stat_slot) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
+    }
+  }
+}
+
+template <typename T, bool DEMOD, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T> a) {
+  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> tw256[256];
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x;
+  {
+    float s, c;
+    sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+    tw256[tid] = mk<T>((T)c, (T)s);
+  }
+  cplx<T> w;
+  {
+    float s, c;
+    sincospif((float)tid * (2.0f / 4096.0f), &s, &c);
+    w = mk<T>((T)c, (T)s);
+  }
+  const BlockItem it = a.items[blockIdx.x];
+  switch (it.wq) {
+    case 1: block_item<T, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    case 2: block_item<T, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    default: block_item<T, 4, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+  }
+}
+
+// taps of a Gabor atom as a 4096-point circular-convolution kernel: g[(-u) mod 4096] = conj(psi(u + 1/2)), |u| <= W
+// (psi of styx_cwt.py:113-144 on the half-integer grid of an even-length record; out[t] = sum_u sig[t + u] conj(psi))
+__global__ void k_block_taps_gabor(double2* __restrict__ g, int w, const double* __restrict__ par, int nb_total,
+                                   const int32_t* __restrict__ ids) {
+  const int j = ids[blockIdx.y];
+  const double p_re = par[j], p_im = par[nb_total + j], omega = par[2 * nb_total + j], amp = par[3 * nb_total + j];
+  double2* row = g + (int64_t)blockIdx.y * kBlk;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < kBlk; m += gridDim.x * blockDim.x) {
+    // m = (-u) mod 4096  ->  u = -m for m <= w, u = 4096 - m for m >= 4096 - w + 1 ... u in [-w, w)
+    int u;
+    bool on = true;
+    if (m <= w) u = -m;
+    else if (m > kBlk - w) u = kBlk - m;
+    else { u = 0; on = false; }
+    double2 v = make_double2(0.0, 0.0);
+    if (on) {
+      const double x = (double)u + 0.5;
+      const double env = amp * exp(-p_re * x * x);
+      const double ph = omega * x - p_im * x * x;
+      double s, c;
+      sincos(ph, &s, &c);
+      v = make_double2(env * c, -env * s);  // conj(psi)
+    }
+    row[m] = v;
+  }
+}
+
+// taps of a Stockwell band: out[t] = e^{-2 pi i idx t / n} sum_tau x[t - tau] wt(tau),  wt(tau) = e^{2 pi i idx tau / n}
+// om(tau), om = IDFT_n of the band's Gaussian window (`om` holds n * om, the unnormalised inverse transform)
+__global__ void k_block_taps_stx(double2* __restrict__ g, int w, const double2* __restrict__ om, int64_t n,
+                                 int64_t idx) {
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < kBlk; m += gridDim.x * blockDim.x) {
+    int tau;
+    bool on = true;
+    if (m < w) tau = m;
+    else if (m > kBlk - w) tau = m - kBlk;
+    else { tau = 0; on = false; }
+    double2 v = make_double2(0.0, 0.0);
+    if (on) {
+      const double2 o = om[tau >= 0 ? tau : n + tau];
+      const int64_t ph = ((idx * (int64_t)tau) % n + n) % n;
+      double s, c;
+      sincospi(2.0 * (double)ph / (double)n, &s, &c);
+      const double inv = 1.0 / (double)n;
+      v = make_double2((o.x * c - o.y * s) * inv, (o.x * s + o.y * c) * inv);
+    }
+    g[m] = v;
+  }
+}
+
+// the Gaussian window of one Stockwell band on the signed FFT bins (styx_stx.py:195-236), as a full row
+__global__ void k_stx_window_row(double2* __restrict__ row, int64_t n, double coef) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    const double ks = (double)(k < (n + 1) / 2 ? k : k - n);
+    const double e = coef * ks;
+    row[k] = make_double2(exp2(-e * e), 0.0);
+  }
+}
+
+template <typename T, bool DEMOD>
+int launch_block_v(const BlockArgs<T>& a, dim3 grid, hipStream_t st) {
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+  if (coef && bits) k_block<T, DEMOD, true, true><<<grid, kBlkThreads, 0, st>>>(a);
+  else if (coef) k_block<T, DEMOD, true, false><<<grid, kBlkThreads, 0, st>>>(a);
+  else if (bits) k_block<T, DEMOD, false, true><<<grid, kBlkThreads, 0, st>>>(a);
+  else k_block<T, DEMOD, false, false><<<grid, kBlkThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+}  // namespace
+
+int block_valid(int wq) { return kBlk - 512 * wq; }
+
+template <>
+int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st) {
+  if (a.nitems <= 0) return QI_OK;
+  dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
+  return demod ? launch_block_v<float, true>(a, grid, st) : launch_block_v<float, false>(a, grid, st);
+}
+
+int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,
+                            hipStream_t st) {
+  dim3 grid(4, (unsigned)count);
+  k_block_taps_gabor<<<grid, 256, 0, st>>>(g, w, d_par, nb_total, d_ids);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st) {
+  k_block_taps_stx<<<4, 256, 0, st>>>(g, w, om, n, idx);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st) {
+  k_stx_window_row<<<(unsigned)(ceil_div(n, 256) > 1024 ? 1024 : ceil_div(n, 256)), 256, 0, st>>>(row, n, coef);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+}  // namespace native
+}  // namespace qi

@@ -22,6 +22,21 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
+// |z|^2 and scaled power in one fixed instruction form, so that every kernel variant (with or without the
+// coefficient / bits stores) rounds the reductions identically
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float norm2(float x, float y) { return fmaf(x, x, __fmul_rn(y, y)); }
+__device__ __forceinline__ double norm2(double x, double y) { return fma(x, x, __dmul_rn(y, y)); }
+
+// complex product in one fixed instruction form (two multiplies, two fused multiply-adds)
+__device__ __forceinline__ float2 cmul_rn(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -__fmul_rn(a.y, b.y)), fmaf(a.x, b.y, __fmul_rn(a.y, b.x)));
+}
+__device__ __forceinline__ double2 cmul_rn(double2 a, double2 b) {
+  return make_double2(fma(a.x, b.x, -__dmul_rn(a.y, b.y)), fma(a.x, b.y, __dmul_rn(a.y, b.x)));
+}
+
 __device__ __forceinline__ float log2_t(float v) { return log2f(v); }
 __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 __device__ __forceinline__ float sqrt_t(float v) { return sqrtf(v); }

@@ -15,86 +15,12 @@
 #include "qi_common.hpp"
 #include "qi_device.hpp"
 #include "qi_native.hpp"
+#include "qi_fft_reg.hpp"
 
 namespace qi {
 namespace native {
 
 namespace {
-
-// cos / sin of 2 pi k / 64, exact at the quadrant points so that trivial twiddles fold away
-constexpr double kCos64[33] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867,
-                               0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476,
-                               0.6343932841636455, 0.5555702330196023, 0.4713967368259978, 0.38268343236508984,
-                               0.29028467725446233, 0.19509032201612833, 0.09801714032956077, 0.0,
-                               -0.09801714032956065, -0.1950903220161282, -0.29028467725446216, -0.3826834323650897,
-                               -0.4713967368259977, -0.555570233019602, -0.6343932841636454, -0.7071067811865475,
-                               -0.773010453362737, -0.8314696123025453, -0.8819212643483549, -0.9238795325112867,
-                               -0.9569403357322088, -0.9807852804032304, -0.9951847266721968, -1.0};
-constexpr double kSin64[33] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898,
-                               0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865475,
-                               0.773010453362737, 0.8314696123025452, 0.8819212643483549, 0.9238795325112867,
-                               0.9569403357322089, 0.9807852804032304, 0.9951847266721968, 1.0, 0.9951847266721969,
-                               0.9807852804032304, 0.9569403357322089, 0.9238795325112867, 0.881921264348355,
-                               0.8314696123025455, 0.7730104533627371, 0.7071067811865476, 0.6343932841636455,
-                               0.5555702330196022, 0.47139673682599786, 0.3826834323650899, 0.2902846772544624,
-                               0.1950903220161286, 0.09801714032956083, 0.0};
-
-// v * W_64^(DIR * K), K in [0, 32)
-template <typename T, int K, int DIR>
-__device__ __forceinline__ cplx<T> mul_tw64(cplx<T> v) {
-  static_assert(K >= 0 && K < 32, "twiddle exponent");
-  if constexpr (K == 0) {
-    return v;
-  } else if constexpr (K == 16) {
-    return DIR > 0 ? mk<T>(-v.y, v.x) : mk<T>(v.y, -v.x);
-  } else {
-    constexpr T c = (T)kCos64[K];
-    constexpr T s = (T)(DIR * kSin64[K]);
-    return mk<T>(v.x * c - v.y * s, v.x * s + v.y * c);
-  }
-}
-
-constexpr int brev(int x, int bits) {
-  int r = 0;
-  for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
-  return r;
-}
-constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
-
-// one radix-2 decimation-in-frequency butterfly of stage S (half span) on register array v[R]
-template <typename T, int R, int S, int DIR, int I>
-__device__ __forceinline__ void bfly(cplx<T> (&v)[R]) {
-  constexpr int i = I % S;
-  constexpr int p = (I / S) * 2 * S;
-  const cplx<T> a = v[p + i], b = v[p + i + S];
-  v[p + i] = mk<T>(a.x + b.x, a.y + b.y);
-  v[p + i + S] = mul_tw64<T, i*(32 / S), DIR>(mk<T>(a.x - b.x, a.y - b.y));
-}
-template <typename T, int R, int S, int DIR, int... Is>
-__device__ __forceinline__ void stage(cplx<T> (&v)[R], std::integer_sequence<int, Is...>) {
-  (bfly<T, R, S, DIR, Is>(v), ...);
-}
-// In-register FFT of R points (R = 2^m <= 64); output index d ends up in v[brev(d)].
-template <typename T, int R, int DIR, int S = R / 2>
-__device__ __forceinline__ void fft_reg(cplx<T> (&v)[R]) {
-  stage<T, R, S, DIR>(v, std::make_integer_sequence<int, R / 2>{});
-  if constexpr (S > 1) fft_reg<T, R, DIR, S / 2>(v);
-}
-
-// v[brev(c)] *= W_64^c for c = 0..31 (the radix-2 combination twiddles of a 2048-point row)
-template <typename T, int... Cs>
-__device__ __forceinline__ void mul_w64_powers(cplx<T> (&v)[32], std::integer_sequence<int, Cs...>) {
-  ((v[brev(Cs, 5)] = mul_tw64<T, Cs, 1>(v[brev(Cs, 5)])), ...);
-}
-
-// exp(+2 pi i m / Lf) for an exact integer phase m in [0, Lf), Lf = 2^p <= 2^24: the float argument
-// 2 m / Lf is exact, so the seeds are accurate to single precision whatever the size of m
-__device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double* c, double* s) {
-  float sf, cf;
-  sincospif((float)m * two_over_len, &sf, &cf);
-  *c = cf;
-  *s = sf;
-}
 
 // Geometry of one workgroup: G = 16 rows of 1024 points, 64 threads per row (1024 threads = 16 waves, <= 128 VGPRs:
 // four waves per SIMD).  The 1024-point row transform is 16 x 16 x 4: step 1, thread (row g, a) transforms
@@ -132,9 +58,6 @@ struct Cfg {
 #else
 #define QI_STAMP(k)
 #endif
-
-__device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
-__device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 
 // ---- loaders: fill A[g][k] (row stride SR) for the G rows of this workgroup ---------------------------------------
 // pruned: A[g][s] = W_Lf^(s t1_g) * sum_m Y[s + 1024 (k1_min + m)] W_N1^((k1_min + m) t1_g),  t1_g = t1_0 + g.
@@ -575,9 +498,9 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       const cplx<T> z = u[brev(c, 4)];
       const uint32_t tt = tb + (uint32_t)i * tstep;
       if (COEF && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
-      const T m2 = z.x * z.x + z.y * z.y;
+      const T m2 = norm2(z.x, z.y);
       if (BITS) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
-      T p = a.power_scale * m2;
+      T p = mul_rn(a.power_scale, m2);
       if (KIND == 1) {
         // short-atom bands evaluated circularly: the first / last `edge` samples are corrected (and reduced) by
         // k_edge_fix afterwards, so they are left out of the sums here.  edge = 0 keeps every sample.
@@ -739,9 +662,9 @@ __global__ void __launch_bounds__(256) k_edge_fix(EdgeArgs<T> a) {
     z.x -= sr;
     z.y -= si;
     if (a.coef) a.coef[row + t] = z;
-    const T m2 = z.x * z.x + z.y * z.y;
+    const T m2 = norm2(z.x, z.y);
     if (a.bits) a.bits[row + t] = log2_t(sqrt_t(m2) + a.eps);
-    a.edge_p[((c * a.nedge + e) * 2 + side) * a.wmax + tloc] = a.power_scale * m2;
+    a.edge_p[((c * a.nedge + e) * 2 + side) * a.wmax + tloc] = mul_rn(a.power_scale, m2);
   }
 }
 
@@ -863,14 +786,6 @@ __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict
 
 }  // namespace
 
-#define QI_LAUNCH_CHECK()                                                                \
-  do {                                                                                   \
-    hipError_t e_ = hipGetLastError();                                                   \
-    if (e_ != hipSuccess) {                                                              \
-      set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
-      return QI_ERR_HIP;                                                                 \
-    }                                                                                    \
-  } while (0)
 
 template <class Kern, typename T>
 static int launch_lds(Kern kern, bool* configured, size_t lds, const RowArgs<T>& a, dim3 grid, int threads,

@@ -80,6 +80,48 @@ struct EdgeArgs {
   T power_scale, eps;
 };
 
+// ---- block engine (qi_block.hip): short-atom bands by overlap-save with 4096-point transforms -------------------
+constexpr int kBlk = 4096;
+struct BlockBand {
+  int32_t out_band;  // row of the panel
+  int32_t bank_row;  // row of the [rows][kBlk] filter-spectrum table
+  int32_t shift;     // Stockwell: shift index idx_j (outputs are multiplied by exp(-2 pi i idx t / n))
+  int32_t pad_;
+  float rot[8];      // Stockwell: r^(2^k), k = 0..3, r = exp(-2 pi i idx 256 / n)
+};
+struct BlockItem {  // one workgroup of the block launch
+  int32_t wq;          // reach group: taps within 256 * wq samples
+  int32_t block;       // block index: outputs [block * V, (block + 1) * V), V = kBlk - 512 wq
+  int32_t band_first, band_count;  // its bands in BlockArgs::bands
+  int32_t plane;       // time_part plane (relative to chunk_base) it writes
+  int32_t stat_slot;   // part_stat slot (relative to stat_base)
+};
+template <typename T>
+struct BlockArgs {
+  int64_t n;
+  int32_t nitems, panel_bands;
+  const BlockItem* items;  // [nitems] device, most expensive first
+  const BlockBand* bands;  // device, all reach groups
+  const cplx<T>* bank;     // [rows][kBlk], scaled by 1 / kBlk
+  const T* sig;            // [C][n]
+  cplx<T>* coef;
+  T* bits;
+  T* time_part;       // [C][chunk_total][n]
+  double* part_band;  // [C][panel_bands][nblk]: slot = block
+  double* part_stat;  // [C][stat_stride][3]: slot = stat_base + item's stat_slot
+  int64_t nblk, stat_stride, stat_base;
+  int32_t chunk_base, chunk_total;
+  T power_scale, eps;
+  float two_over_n;
+};
+int block_valid(int wq);  // outputs per block for taps within 256 * wq samples
+template <typename T>
+int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st);
+int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,
+                            hipStream_t st);
+int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);
+int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
+
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                        hipStream_t st);

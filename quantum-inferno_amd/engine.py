@@ -190,9 +190,20 @@ class TfrPlan:
 
     # -- transforms ---------------------------------------------------------------------------
     # -- measurement --------------------------------------------------------------------------
-    def profile(self, enable=True):
-        """Time every stage launch with HIP events on the current stream (qi_plan_profile)."""
-        _lib.check(self._lib.qi_plan_profile(self._handle, 1 if enable else 0))
+    def profile(self, enable=True, stages=None):
+        """Time stage launches with HIP events on the current stream (qi_plan_profile): every stage, or only the
+        named ones (`stages`, names from `_lib.STAGES`) -- each recorded event is a small bubble in the stream."""
+        code = 1 if enable else 0
+        if enable and stages is not None:
+            code = 0
+            for name in stages:
+                code |= 1 << (_lib.STAGES.index(name) + 1)
+        _lib.check(self._lib.qi_plan_profile(self._handle, code))
+
+    def stage_bands(self, stage):
+        """Bands (over the styx, atoms and Stockwell tables) whose coefficients the kernels of `stage` produce."""
+        k = _lib.STAGES.index(stage)
+        return [int(self._lib.qi_plan_stage_bands(self._handle, which, k)) for which in (0, 1, 2)]
 
     def profile_read(self):
         """{stage name: (total ms, launches)} since the last read (qi_plan_profile_read)."""
