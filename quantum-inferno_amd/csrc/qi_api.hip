@@ -258,7 +258,7 @@ struct qi_plan {
   int32_t nedge = 0;
   int64_t edge_wmax = 0;
   int native_short = 1;  // evaluate short-atom styx bands circularly at length n (0: everything at 2n)
-  int64_t native_kmax = 8192;  // widest spectrum support handled by the one-pass (pruned) loader
+  int64_t native_kmax = 12288;  // widest spectrum support handled by the one-pass (pruned) loader
   int native_debug = 0;
   int native_fwd = 1;          // forward transform of the records on the native kernels (0: hipFFT)
   int native_wgs = 256;        // workgroups a pass-2 launch should have at least (band chunks are sized for it)

@@ -830,10 +830,9 @@ int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, h
 }
 
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
-template <>
-int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
-  using C1 = Cfg<float>;
-  using C2 = Cfg<float>;
+template <class C1>
+static int launch_forward_cfg(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
+  using C2 = C1;
   dim3 g1((unsigned)(a.N2 / C1::G), 1, (unsigned)n_channels);
   if (a.N1 == 1024)
     QI_TRY((launch_p1<float, C1, 2, 1>(a, g1, st)));
@@ -854,6 +853,12 @@ int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_chann
   kern<<<g2, C2::TH, C2::LDS_BYTES, st>>>(a, Xout);
   QI_LAUNCH_CHECK();
   return QI_OK;
+}
+template <>
+int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
+  // few records: 8-row workgroups, twice as many of them (a launch of 16-row workgroups would leave most CUs idle)
+  if (n_channels * (a.N2 / 16) < 256) return launch_forward_cfg<Cfg<float, 8>>(a, Xout, n_channels, st);
+  return launch_forward_cfg<Cfg<float, 16>>(a, Xout, n_channels, st);
 }
 
 template <class C>

@@ -14,23 +14,41 @@ def shard(total, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+def reduced_slots(n_channels, n_bands, n, time_dtype=torch.float32):
+    """float64 slots of one result's reduced product: power_band [C, B] f64 | stats [C, 4] f64 | power_time [C, n]
+    in the record dtype (float32 takes half a slot per sample)."""
+    tbytes = n_channels * n * torch.empty((), dtype=time_dtype).element_size()
+    return n_channels * n_bands + n_channels * 4 + (tbytes + 7) // 8
+
+
 def pack_reduced(results):
-    """Flatten the reduced product of several TfrResult into one float64 buffer per rank:
-    per result [C, B + n + 4] = power_band | power_time | stats."""
+    """The reduced product of several TfrResult as ONE float64 buffer per rank (layout: reduced_slots).  Results made
+    by TfrPlan already own such a buffer (`reduced`: their power_band / stats / power_time are views into it), so this
+    is at most one concatenation."""
     parts = []
     for r in results:
-        parts.append(torch.cat([r.power_band, r.power_time.to(torch.float64), r.stats], dim=1).reshape(-1))
-    return torch.cat(parts)
+        blob = getattr(r, "reduced", None)
+        if blob is None:
+            t = r.power_time.contiguous().reshape(-1)
+            pad = ((-t.numel() * t.element_size()) % 8) // t.element_size()
+            if pad:
+                t = torch.cat([t, t.new_zeros(pad)])
+            blob = torch.cat([r.power_band.reshape(-1), r.stats.reshape(-1), t.view(torch.float64)])
+        parts.append(blob)
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
-def unpack_reduced(flat, n_channels, shapes):
-    """Inverse of pack_reduced: shapes = [(B, n), ...] -> list of (power_band, power_time, stats)."""
+def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):
+    """Inverse of pack_reduced: shapes = [(B, n), ...] -> list of (power_band, power_time, stats) views."""
     out, pos = [], 0
     for n_b, n in shapes:
-        width = n_b + n + 4
-        block = flat[pos : pos + n_channels * width].reshape(n_channels, width)
-        out.append((block[:, :n_b], block[:, n_b : n_b + n], block[:, n_b + n :]))
-        pos += n_channels * width
+        slots = reduced_slots(n_channels, n_b, n, time_dtype)
+        block = flat[pos : pos + slots]
+        band = block[: n_channels * n_b].reshape(n_channels, n_b)
+        stats = block[n_channels * n_b : n_channels * (n_b + 4)].reshape(n_channels, 4)
+        time = block[n_channels * (n_b + 4) :].view(time_dtype)[: n_channels * n].reshape(n_channels, n)
+        out.append((band, time, stats))
+        pos += slots
     return out
 
 

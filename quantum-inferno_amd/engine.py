@@ -77,6 +77,7 @@ class TfrResult:
     power_time: Optional[torch.Tensor] = None  # [C, n], sum over bands of P
     stats: Optional[torch.Tensor] = None  # [C, 4] float64: max P, sum P, sum P log2 P, 0
     power_scale: float = 1.0
+    reduced: Optional[torch.Tensor] = None  # float64 buffer the three reductions are views of (dist.reduced_slots)
 
     @property
     def max_power(self):
@@ -235,9 +236,15 @@ class TfrPlan:
             if bits:
                 res.bits = torch.empty((n_ch, n_b, self.n), dtype=self.rdtype, device=dev)
             if reductions:
-                res.power_band = torch.empty((n_ch, n_b), dtype=torch.float64, device=dev)
-                res.power_time = torch.empty((n_ch, self.n), dtype=self.rdtype, device=dev)
-                res.stats = torch.empty((n_ch, 4), dtype=torch.float64, device=dev)
+                # one buffer for the whole reduced product (the message of dist.gather_reduced); the three outputs
+                # are views into it
+                from .dist import reduced_slots
+
+                res.reduced = torch.empty(reduced_slots(n_ch, n_b, self.n, self.rdtype), dtype=torch.float64, device=dev)
+                o1, o2 = n_ch * n_b, n_ch * (n_b + 4)
+                res.power_band = res.reduced[:o1].view(n_ch, n_b)
+                res.stats = res.reduced[o1:o2].view(n_ch, 4)
+                res.power_time = res.reduced[o2:].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
         out = _lib.TfrOut(
             coef=_lib.ptr(res.coef),
             bits=_lib.ptr(res.bits),

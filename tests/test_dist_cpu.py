@@ -65,14 +65,15 @@ def test_gather_of_reduced_product_world2(tmp_path):
     sys.path.insert(0, ROOT)
     from quantum_inferno_amd import dist as qdist
 
-    assert got.shape == (world, 2 * 3 * (n_b + n + 4))
+    assert got.shape == (world, 2 * qdist.reduced_slots(3, n_b, n, torch.float32))
     for rank in range(world):
         first, count = qdist.shard(total_ch, rank, world)
         parts = qdist.unpack_reduced(got[rank], count, [(n_b, n), (n_b, n)])
         for panel, (band, time, stats) in enumerate(parts):
             ch = torch.arange(first, first + count, dtype=torch.float64).reshape(-1, 1)
             assert torch.equal(band, ch * 1000 + panel * 100 + torch.arange(n_b, dtype=torch.float64)[None, :])
-            assert torch.allclose(time, ch * 10 + panel + torch.arange(n, dtype=torch.float64)[None, :] / n, atol=1e-6)
+            assert time.dtype == torch.float32
+            assert torch.allclose(time.double(), ch * 10 + panel + torch.arange(n, dtype=torch.float64)[None, :] / n, atol=1e-5)
             assert torch.equal(stats[:, 0:1], ch + panel) and torch.equal(stats[:, 2:3], ch * 3)
 
 
