@@ -263,6 +263,7 @@ struct qi_plan {
   int native_fwd = 1;          // forward transform of the records on the native kernels (0: hipFFT)
   int native_wgs = 256;        // workgroups a pass-2 launch should have at least (band chunks are sized for it)
   unsigned long long* stamps = nullptr;  // diagnostic builds: phase cycle counters of the last pass-2 launch
+  unsigned long long* blk_stamps = nullptr;  // idem, last block launch
   int native_group = 0;        // wide bands per launch group (0: all in one group)
   int native_rows = 16;        // consecutive time residues (rows) per pass-2 workgroup: 8 or 16
 };
@@ -960,6 +961,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       b.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       b.two_over_n = (float)(2.0 / (double)n);
+      b.debug = p->native_debug;
+      b.stamps = p->blk_stamps;
       p->prof.begin(st, QI_STAGE_BLOCK);
       QI_TRY(native::launch_block<T>(b, bt.demod, ct, st));
       p->prof.end(QI_STAGE_BLOCK, st);
@@ -1106,6 +1109,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (getenv("QI_NATIVE_STAMPS")) {
     if (hipMalloc((void**)&p->stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->stamps = nullptr;
     if (p->stamps) (void)hipMemset(p->stamps, 0, 65536 * 8 * sizeof(unsigned long long));
+    if (hipMalloc((void**)&p->blk_stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->blk_stamps = nullptr;
+    if (p->blk_stamps) (void)hipMemset(p->blk_stamps, 0, 65536 * 8 * sizeof(unsigned long long));
   }
 #endif
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
@@ -1149,6 +1154,24 @@ int qi_plan_destroy(qi_plan* p) {
               sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt);
     }
     (void)hipFree(p->stamps);
+  }
+  if (p->blk_stamps) {
+    std::vector<unsigned long long> h(65536 * 8);
+    if (hipMemcpy(h.data(), p->blk_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum[8] = {0};
+      long cnt = 0;
+      for (size_t w = 0; w < 65536; ++w) {
+        if (!h[w * 8 + 5]) continue;
+        ++cnt;
+        for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k];
+      }
+      if (cnt)
+        fprintf(stderr, "[qi stamps] last block launch, %ld workgroups, %.2f bands each; mean cycles per workgroup: prologue "
+                "(load + forward) %.0f | per band: filter loads issued %.0f | wait for them %.0f | multiply + inverse "
+                "transform %.0f | epilogue %.0f\n", cnt, sum[5] / cnt, sum[0] / cnt, sum[1] / sum[5], sum[2] / sum[5],
+                sum[3] / sum[5], sum[4] / sum[5]);
+    }
+    (void)hipFree(p->blk_stamps);
   }
 #endif
   for (auto& t : p->nat) t.release();

@@ -28,11 +28,37 @@ constexpr int kBlkThreads = 256;
 #ifndef QI_BLK_WAVES
 #define QI_BLK_WAVES 3  // waves per SIMD the block kernel is compiled for (register budget 512 / QI_BLK_WAVES)
 #endif
+#ifdef QI_NATIVE_DEBUG
+#define QI_BDBG(bit) (a.debug & (bit))
+#else
+#define QI_BDBG(bit) false
+#endif
+#ifdef QI_NATIVE_STAMPS
+#define QI_BSTAMP(k)                                               \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+    st_acc[k] += now_ - st_last;                                   \
+    st_last = now_;                                                \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  } while (0)
+#else
+#define QI_BSTAMP(k)
+#endif
 constexpr int kBlkPad = 257;  // k0-stride of the second exchange image (conflict-free transposed reads)
 
 template <typename T>
 __device__ __forceinline__ cplx<T> cconj(cplx<T> v) {
   return mk<T>(v.x, -v.y);
+}
+
+// exchange between the half-waves: afterwards lanes 0-31 hold (their own a, the a of lane + 32) and lanes 32-63
+// (the b of lane - 32, their own b)
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
 }
 
 // v[brev(q)] *= w^q, q = 1..15, powers by products of w, w^2, w^4, w^8 (depth <= 4 roundings)
@@ -59,9 +85,13 @@ __device__ __forceinline__ void mul_powers16(cplx<T> (&v)[16], cplx<T> w) {
 
 // 4096-point transform of the workgroup's block.  Entry: v[b] = in[tid + 256 b]; exit: v[brev(c)] = out[tid + 256 c].
 // `w` = W4096^tid (inverse sign), `tw256[m]` = W256^m (inverse sign); DIR = -1 conjugates both.
+// Column order: the thread of lane L in wave wv owns column col = 64 wv + (L < 32 ? 2 L : 2 (L - 32) + 1) on entry
+// and on exit, i.e. lanes L and L + 32 hold ADJACENT samples -- after one v_permlane32_swap per register pair a lane
+// holds two adjacent outputs and stores them as 16 bytes (the epilogue is store-issue bound: half the store
+// instructions).  `w` = W4096^col.
 template <typename T, int DIR>
 __device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
-                                        cplx<T> w, int tid) {
+                                        cplx<T> w, int tid, int col) {
   fft_reg<T, 16, DIR>(v);  // over k2 -> q2
   // the powers of w do not depend on the band: hide that from the optimiser, which would otherwise keep all fifteen
   // in registers across the band loop
@@ -73,7 +103,7 @@ __device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ 
 #pragma unroll
     for (int q2 = 0; q2 < 16; ++q2) t[q2] = v[brev(q2, 4)];
 #pragma unroll
-    for (int q2 = 0; q2 < 16; ++q2) buf[q2 * 256 + tid] = t[q2];
+    for (int q2 = 0; q2 < 16; ++q2) buf[q2 * 256 + col] = t[q2];
   }
   __syncthreads();
   const int k0 = tid & 15, q2t = tid >> 4;
@@ -87,7 +117,8 @@ __device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ 
   }
   __syncthreads();
 #pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) buf[k0 * kBlkPad + q1 * 16 + q2t] = v[brev(q1, 4)];
+  for (int q1 = 0; q1 < 16; ++q1)  // column 16 q1 + q2t goes to the slot of the thread that owns it (see above)
+    buf[k0 * kBlkPad + 64 * (q1 >> 2) + 8 * (q1 & 3) + 32 * (q2t & 1) + (q2t >> 1)] = v[brev(q1, 4)];
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) v[k] = buf[k * kBlkPad + tid];
@@ -103,8 +134,13 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
                                            cplx<T> w) {
   constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // the column this thread owns
   const int64_t blk = it.block, ch = blockIdx.z;
   const int64_t n = a.n;
+#ifdef QI_NATIVE_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   // record samples [t0, t0 + 4096), outputs [t0 + W, t0 + W + V)
   const int64_t t0 = blk * V - W;
   cplx<T> S[16];
@@ -112,7 +148,7 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
     const T* __restrict__ sig = a.sig + ch * n;
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-      int64_t t = t0 + tid + 256 * b;
+      int64_t t = t0 + col + 256 * b;
       T x;
       if (DEMOD) {
         t = (t + n) & (n - 1);  // circular (n is a power of two, t >= -n)
@@ -122,7 +158,7 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
       }
       S[b] = mk<T>(x, T(0));
     }
-    fft4096<T, -1>(S, buf, tw256, w, tid);
+    fft4096<T, -1>(S, buf, tw256, w, tid, col);
     cplx<T> t[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
@@ -130,26 +166,38 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
     for (int c = 0; c < 16; ++c) S[c] = t[c];
   }
 
-  T col[NOUT];
+  QI_BSTAMP(0);
+  T col_p[NOUT];  // per-time power sums of this thread's outputs
 #pragma unroll
-  for (int i = 0; i < NOUT; ++i) col[i] = T(0);
+  for (int i = 0; i < NOUT; ++i) col_p[i] = T(0);
   T mx = T(0);
   double plogp = 0.0;
-  const uint32_t tb0 = (uint32_t)(t0 + W + tid);  // this thread's first output sample
+  const uint32_t tb0 = (uint32_t)(t0 + W + col);  // this thread's first output sample
+  // the 16-byte stores: lanes 0-31 write the pair (own, lane + 32) of output i, lanes 32-63 the pair of output i + 1
+  const uint32_t tb_pair = (uint32_t)(t0 + W + kWave * wv + 2 * (lane & 31)) + (lane < 32 ? 0u : 256u);
   int pending = -1, par = 0;  // band whose wave sums sit in s_red[par ^ 1] until a barrier has passed
 
+  // the band descriptor is fetched one band ahead: its load would otherwise sit in front of the filter loads
+  BlockBand bd_next = a.bands[it.band_first];
   for (int jj = 0; jj < it.band_count; ++jj) {
-    const BlockBand bd = a.bands[it.band_first + jj];
+    const BlockBand bd = bd_next;
+    if (jj + 1 < it.band_count) bd_next = a.bands[it.band_first + jj + 1];
     cplx<T> v[16];
     {
-      const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + tid;
+      const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + col;
       cplx<T> h[16];
 #pragma unroll
-      for (int b = 0; b < 16; ++b) h[b] = H[256 * b];
+      for (int b = 0; b < 16; ++b) h[b] = QI_BDBG(2) ? S[(b + 1) & 15] : H[256 * b];
+      QI_BSTAMP(1);
+#ifdef QI_NATIVE_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      QI_BSTAMP(2);
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    fft4096<T, 1>(v, buf, tw256, w, tid);
+    if (!QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;
       for (int q = 0; q < NW; ++q) r += s_red[par ^ 1][q];
@@ -180,21 +228,38 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
         rot[i] = cmul_rn(rot[i - low], mk<T>((T)bd.rot[2 * k], (T)bd.rot[2 * k + 1]));
       }
     }
+    uint32_t tp = tb_pair;
+    asm volatile("" : "+v"(tp));
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) {
-      const int c = i + WQ;
-      cplx<T> z = v[brev(c, 4)];
-      if (DEMOD) z = cmul_rn(z, rot[i]);
-      const uint32_t tt = tb + 256u * (uint32_t)i;
+    for (int i = 0; i < NOUT; i += 2) {
+      cplx<T> z[2];
+      T lg[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        z[h] = v[brev(i + h + WQ, 4)];
+        if (DEMOD) z[h] = cmul_rn(z[h], rot[i + h]);
+        const bool inside = tb + 256u * (uint32_t)(i + h) < (uint32_t)n;
+        const T m2 = norm2(z[h].x, z[h].y);
+        if (BITS) lg[h] = log2_t(sqrt_t(m2) + a.eps);
+        const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
+        col_p[i + h] += p;
+        rowacc += p;
+        mx = p > mx ? p : mx;
+        pl += plog2p(p);
+      }
+      const uint32_t tt = tp + 256u * (uint32_t)i;  // first sample of this lane's 16-byte pair
       const bool inside = tt < (uint32_t)n;
-      if (COEF && inside) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
-      const T m2 = norm2(z.x, z.y);
-      if (BITS && inside) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
-      const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
-      col[i] += p;
-      rowacc += p;
-      mx = p > mx ? p : mx;
-      pl += plog2p(p);
+      if (COEF) {
+        half_swap(z[0].x, z[1].x);
+        half_swap(z[0].y, z[1].y);
+        if (inside && !QI_BDBG(1))
+          *reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) =
+              make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+      }
+      if (BITS) {
+        half_swap(lg[0], lg[1]);
+        if (inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
+      }
     }
     plogp += (double)pl;
     if (a.part_band) {
@@ -203,16 +268,26 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
       pending = bd.out_band;
       par ^= 1;
     }
+    QI_BSTAMP(4);
   }
+#ifdef QI_NATIVE_STAMPS
+  if (a.stamps && tid == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    for (int k = 0; k < 5; ++k) o[k] = st_acc[k];
+    o[5] = (unsigned long long)it.band_count;
+  }
+#endif
 
   T tot = T(0);
   char* __restrict__ time_row = reinterpret_cast<char*>(
       a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + it.plane) * n : nullptr);
 #pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    tot += col[i];
-    const uint32_t tt = tb0 + 256u * (uint32_t)i;
-    if (time_row && tt < (uint32_t)n) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = col[i];
+  for (int i = 0; i < NOUT; i += 2) {
+    tot += col_p[i] + col_p[i + 1];
+    T c0 = col_p[i], c1 = col_p[i + 1];
+    half_swap(c0, c1);
+    const uint32_t tt = tb_pair + 256u * (uint32_t)i;
+    if (time_row && tt < (uint32_t)n) *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(c0, c1);
   }
   const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
   __syncthreads();  // the last band's wave sums are visible; buf is free
@@ -258,7 +333,9 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   cplx<T> w;
   {
     float s, c;
-    sincospif((float)tid * (2.0f / 4096.0f), &s, &c);
+    const int lane = tid & (kWave - 1);
+    const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // block_item's column order
+    sincospif((float)col * (2.0f / 4096.0f), &s, &c);
     w = mk<T>((T)c, (T)s);
   }
   const BlockItem it = a.items[blockIdx.x];

@@ -817,16 +817,20 @@ static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
   return a.bits ? launch_p2v<T, C, KIND, false, true>(a, grid, st) : launch_p2v<T, C, KIND, false, false>(a, grid, st);
 }
 
-template <>
-int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
-  if (a.ngen_launch <= 0) return QI_OK;
-  using C = Cfg<float>;
+template <class C>
+static int launch_pass1_cfg(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
   dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
   const bool stx = kind == 2;
   if (a.N1 == 1024) return stx ? launch_p1<float, C, 1, 1>(a, grid, st) : launch_p1<float, C, 0, 1>(a, grid, st);
   if (a.N1 == 2048) return stx ? launch_p1<float, C, 1, 2>(a, grid, st) : launch_p1<float, C, 0, 2>(a, grid, st);
   set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
   return QI_ERR_UNSUPPORTED;
+}
+template <>
+int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
+  if (a.ngen_launch <= 0) return QI_OK;
+  // (8-row workgroups were measured for launches that do not cover the chip: slower, their 64-byte runs cost more)
+  return launch_pass1_cfg<Cfg<float, 16>>(a, kind, n_channels, st);
 }
 
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)

@@ -113,6 +113,8 @@ struct BlockArgs {
   int32_t chunk_base, chunk_total;
   T power_scale, eps;
   float two_over_n;
+  int32_t debug;  // QI_NATIVE_DEBUG bit mask (timing experiments only: 1 no stores, 2 no filter loads, 4 no inverse FFT)
+  unsigned long long* stamps;  // diagnostic builds only (-DQI_NATIVE_STAMPS): [workgroup][8] phase cycles
 };
 int block_valid(int wq);  // outputs per block for taps within 256 * wq samples
 template <typename T>
