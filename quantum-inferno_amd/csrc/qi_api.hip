@@ -226,7 +226,10 @@ struct qi_plan {
     std::vector<NativeGroup> groups;
     void* Hc = nullptr;
     void* Hfull = nullptr;
+    native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip)
+    int32_t nzoom = 0;
     void release() {
+      if (d_zoom) (void)hipFree(d_zoom);
       if (d_bands) (void)hipFree(d_bands);
       if (d_gen_list) (void)hipFree(d_gen_list);
       if (Hc) (void)hipFree(Hc);
@@ -253,6 +256,9 @@ struct qi_plan {
     }
   } blk[3];
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
+  int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
+  int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
+  float* d_zoom_w[2] = {nullptr, nullptr};  // interpolation weights for lane offsets 0 and 1
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
@@ -414,7 +420,26 @@ bool native_wanted(const qi_plan* p, int kind) {
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
 int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
-  if (bands.empty()) {  // every band is produced by the block engine: an empty but valid table
+  // narrow-spectrum bands go to the zoom engine: support at most 1 / kZoomOversample of the coarse grid
+  if (p->native_zoom && kind != 3 && Lf % native::kZoomD == 0 && p->n % (native::kZoomD * native::kZoomSteps * 4) == 0) {
+    const int64_t M = Lf / native::kZoomD;
+    std::vector<native::BandDesc> zoom, rest;
+    for (const auto& d : bands) (d.mode == 0 && d.k_len <= M / native::kZoomOversample ? zoom : rest).push_back(d);
+    if (!zoom.empty()) {
+      QI_HIP(hipMalloc((void**)&t.d_zoom, zoom.size() * sizeof(native::BandDesc)));
+      QI_HIP(hipMemcpy(t.d_zoom, zoom.data(), zoom.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
+      t.nzoom = (int32_t)zoom.size();
+      for (int e = 0; e < 2; ++e) {
+        if (p->d_zoom_w[e]) continue;
+        std::vector<float> w((size_t)native::kZoomD * native::kZoomTaps);
+        native::zoom_weights(e, w.data());
+        QI_HIP(hipMalloc((void**)&p->d_zoom_w[e], w.size() * sizeof(float)));
+        QI_HIP(hipMemcpy(p->d_zoom_w[e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
+      bands.swap(rest);
+    }
+  }
+  if (bands.empty()) {  // every band is produced by the block / zoom engines: an empty but valid table
     t.Lf = Lf;
     t.ready = true;
     return QI_OK;
@@ -823,13 +848,28 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     blk_stats = bt.nitems;
     blk_slots = bt.max_blocks;
   }
+  // zoom engine launch (narrow bands of the main table): its chunks come last
+  const auto& zt = p->nat[kind];
+  const bool zoom = zt.nzoom > 0;
+  const int64_t zwaves = zoom ? native::zoom_waves(n) : 0;
+  const int64_t zM = zoom ? zt.Lf / native::kZoomD : 0;
+  int znchunk = 0;
+  const int chunk_z0 = chunk_total;
+  if (zoom) {
+    znchunk = (int)ceil_div(p->native_zoom_waves, zwaves * C);
+    if (znchunk < 1) znchunk = 1;
+    if (znchunk > zt.nzoom) znchunk = zt.nzoom;
+    chunk_total += znchunk;
+  }
+  const int64_t zoom_stats = (int64_t)znchunk * zwaves;
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
   if (blk_slots > nbk) nbk = blk_slots;
-  const int64_t stat_slots = (int64_t)chunk_p2 * nbk + blk_stats + (shorts ? p->nedge : 0);
+  if (zwaves > nbk) nbk = zwaves;
+  const int64_t stat_slots = (int64_t)chunk_p2 * nbk + blk_stats + zoom_stats + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
-  const bool clear_parts = subs.size() > 1 || blocks;
+  const bool clear_parts = subs.size() > 1 || blocks || zoom;
   // scratch regions, each [Ct][...] without per-channel padding
   const size_t e_x = (size_t)Lf0 * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
@@ -840,7 +880,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
-  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez;
+  const size_t e_zc = zoom ? (size_t)zt.nzoom * zM * sizeof(cplx<T>) : 0;
+  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_zc;
   if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
               per_chan + 4096);
@@ -865,6 +906,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   T* edge_p = reinterpret_cast<T*>(carve(e_ep));
   T* edge_time = reinterpret_cast<T*>(carve(e_et));
   cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
+  cplx<T>* zcoarse = e_zc ? reinterpret_cast<cplx<T>*>(carve(e_zc)) : nullptr;
 
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
@@ -938,6 +980,42 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         p->prof.end(QI_STAGE_PASS2, st);
         chunk_base += sb.nchunk[g];
       }
+    }
+    if (zoom) {
+      native::ZoomArgs<T> z{};
+      z.n = n;
+      z.Lf = zt.Lf;
+      z.M = zM;
+      z.nbands = zt.nzoom;
+      z.panel_bands = (int32_t)B;
+      z.bands = zt.d_zoom;
+      z.X = X;
+      z.Hc = static_cast<const cplx<T>*>(zt.Hc);
+      z.coarse = zcoarse;
+      z.stx = kind == 2 ? 1 : 0;
+      // panel sample t is full-length sample t + off: linear correlation off = n/2 - 1, rolled circular n/2, Stockwell 0
+      z.lane_off = kind == 0 ? 1 : 0;
+      z.tau_off = kind == 2 ? 0 : n / 2 / native::kZoomD;
+      z.weights = p->d_zoom_w[z.lane_off];
+      z.inv_len = (T)(1.0 / (double)zt.Lf);
+      z.two_over_len = (float)(2.0 / (double)zt.Lf);
+      z.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      z.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      z.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+      z.part_band = want_band ? part_band : nullptr;
+      z.part_stat = want_stat ? part_stat : nullptr;
+      z.nblk = nbk;
+      z.stat_stride = stat_slots;
+      z.stat_base = (int64_t)chunk_p2 * nbk + blk_stats;
+      z.chunk_base = chunk_z0;
+      z.chunk_total = chunk_total;
+      z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      p->prof.begin(st, QI_STAGE_ZOOM);
+      QI_TRY(native::launch_zoom_gather<T>(z, ct, st));
+      QI_TRY(fft_c2c<T>(p->fft, zcoarse, zM, ct * zt.nzoom, HIPFFT_BACKWARD, st));
+      QI_TRY(native::launch_zoom<T>(z, znchunk, ct, st));
+      p->prof.end(QI_STAGE_ZOOM, st);
     }
     if (blocks) {
       native::BlockArgs<T> b{};
@@ -1115,6 +1193,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
 #endif
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -1176,6 +1256,8 @@ int qi_plan_destroy(qi_plan* p) {
 #endif
   for (auto& t : p->nat) t.release();
   for (auto& t : p->blk) t.release();
+  for (auto* w : p->d_zoom_w)
+    if (w) (void)hipFree(w);
   if (p->d_edge) (void)hipFree(p->d_edge);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
@@ -1344,8 +1426,10 @@ int64_t qi_plan_stage_bands(const qi_plan* p, int which, int stage) {
   if (!p->nat[which].ready) return stage == QI_STAGE_INVERSE ? total : 0;
   int64_t blk = 0;
   if (which != 1 && p->blk[which].ready) blk = p->blk[which].rows;
+  const int64_t zoom = p->nat[which].nzoom;
   if (stage == QI_STAGE_BLOCK) return blk;
-  return stage == QI_STAGE_PASS2 ? total - blk : 0;
+  if (stage == QI_STAGE_ZOOM) return zoom;
+  return stage == QI_STAGE_PASS2 ? total - blk - zoom : 0;
 }
 
 int qi_plan_profile(qi_plan* p, int enable) {

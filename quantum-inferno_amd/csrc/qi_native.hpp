@@ -124,6 +124,41 @@ int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);
 int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
 
+// ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
+constexpr int kZoomD = 64;      // fine samples per coarse sample (one wave lane per fine position)
+constexpr int kZoomTaps = 13;   // interpolation taps: 12-tap Kaiser-windowed sinc, one more for the half-open phase range
+constexpr int kZoomSteps = 16;  // coarse steps (of 64 outputs each) one wave produces per band
+constexpr int kZoomOversample = 4;  // a band qualifies if its support is at most M / kZoomOversample bins
+template <typename T>
+struct ZoomArgs {
+  int64_t n, Lf, M;        // M = Lf / kZoomD coarse samples per band
+  int32_t nbands, panel_bands;
+  const BandDesc* bands;   // [nbands] device: one-pass ("pruned") descriptors of the zoom bands
+  const cplx<T>* X;        // [C][Lf] spectra of the records
+  const cplx<T>* Hc;       // compact bank (Gabor kinds)
+  cplx<T>* coarse;         // [C][nbands][M]: baseband spectra, then (after the batched inverse FFT) coarse samples
+  const float* weights;    // [kZoomD][kZoomTaps] interpolation weights of the lanes
+  int32_t stx;             // Stockwell: bands are at baseband already, no carrier
+  int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
+  int64_t tau_off;
+  T inv_len;
+  float two_over_len;
+  cplx<T>* coef;
+  T* bits;
+  T* time_part;       // [C][chunk_total][n]
+  double* part_band;  // [C][panel_bands][nblk]: slot = wave index along time
+  double* part_stat;  // [C][stat_stride][3]: slot = stat_base + chunk * waves + wave
+  int64_t nblk, stat_stride, stat_base;
+  int32_t chunk_base, chunk_total;
+  T power_scale, eps;
+};
+int64_t zoom_waves(int64_t n);  // waves along time (partial slots per band, stat slots per chunk)
+template <typename T>
+int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
+template <typename T>
+int launch_zoom(const ZoomArgs<T>& a, int nchunk, int64_t n_channels, hipStream_t st);
+void zoom_weights(int lane_off, float* w /*[kZoomD][kZoomTaps]*/);
+
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                        hipStream_t st);

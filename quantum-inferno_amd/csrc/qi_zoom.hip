@@ -1,0 +1,227 @@
+// Zoom engine: the narrow-spectrum bands of a panel (long atoms: a few hundred to a few thousand occupied bins out of
+// a million) are slowly varying envelopes on a carrier.  Their occupied bins, moved to baseband, are transformed on a
+// COARSE time grid of M = Lf / 64 samples (one small batched inverse FFT per band), and the panel is produced from
+// that by band-limited interpolation -- a 12-tap Kaiser-windowed sinc on the >= 4x oversampled coarse grid, error
+// below 6e-7 of a unit tone at the band edge (where the spectrum is < 2^-30 of its peak), < 1e-9 in the bulk -- times
+// the carrier phasor.  About 50 instructions per output instead of a share of a million-point transform, nothing
+// discarded (the zero-padded half of the linear correlation is simply not evaluated), no intermediate: the kernel
+// is bound by the panel write.
+//
+// One wave = 64 lanes = the 64 fine positions between two coarse samples: lane L produces sample 64 tau + L for
+// kSteps consecutive tau; the coarse samples a step needs are uniform over the wave (scalar registers, taken from a
+// vector register by v_readlane), the 13 interpolation weights are per-lane constants, every store is a 512-byte
+// run.  Waves are independent: no LDS, no barriers.  No MFMA: there is no dense contraction here.
+#include "qi_common.hpp"
+#include "qi_device.hpp"
+#include "qi_native.hpp"
+#include "qi_fft_reg.hpp"
+
+namespace qi {
+namespace native {
+
+namespace {
+
+constexpr int kZoomThreads = 256;
+
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+
+// Baseband spectra of the zoom bands: coarse[c][j][kappa mod M] = Y_j[k_c + kappa] for the band's support, 0 elsewhere
+// (Y as the one-pass loader of qi_native.hip forms it: spectrum x compact bank, or shifted spectrum x Gaussian).
+template <typename T, bool STX>
+__global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
+  const int64_t kappa = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (kappa >= a.M) return;
+  const int j = blockIdx.y;
+  const int64_t ch = blockIdx.z;
+  const BandDesc bd = a.bands[j];
+  const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
+  const int32_t ks = (int32_t)(kappa < a.M / 2 ? kappa : kappa - a.M);
+  const int32_t k = kc + ks;
+  cplx<T> y = mk<T>(T(0), T(0));
+  if (k >= bd.k_lo && k < bd.k_lo + bd.k_len) {
+    const cplx<T>* __restrict__ X = a.X + ch * a.Lf;
+    if (STX) {
+      const uint32_t mask = (uint32_t)a.Lf - 1u;
+      const cplx<T> x = X[(uint32_t)(k + (int32_t)bd.shift) & mask];
+      const T e = (T)bd.coef * (T)k;
+      const T w = exp2_t(-e * e) * a.inv_len;
+      y = mk<T>(x.x * w, x.y * w);
+    } else {
+      y = cmul(X[k], a.Hc[bd.src_off + (k - bd.k_lo)]);
+    }
+  }
+  a.coarse[((int64_t)ch * a.nbands + j) * a.M + kappa] = y;
+}
+
+// Fine stage.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands are at
+// baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
+template <typename T, int STEPS, bool PHASOR, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
+  constexpr int NW = kZoomThreads / kWave, TAPS = kZoomTaps;
+  static_assert(STEPS + TAPS - 1 <= kWave, "the window of one wave must fit its lanes");
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int64_t ch = blockIdx.z;
+  const int64_t gw = (int64_t)blockIdx.x * NW + wv;  // wave index along time
+  const uint32_t tau_a = (uint32_t)gw * STEPS;       // first coarse step of this wave
+  const uint32_t mmask = (uint32_t)a.M - 1u, lmask = (uint32_t)a.Lf - 1u;
+  float wgt[TAPS];
+#pragma unroll
+  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[lane * TAPS + j];
+  T colp[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) colp[s] = T(0);
+  T mx = T(0);
+  double plogp = 0.0;
+  const uint32_t t_base = tau_a * kZoomD + (uint32_t)lane;  // output sample of step s: t_base + 64 s
+
+  for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
+    const BandDesc bd = a.bands[jj];
+    const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.nbands + jj) * a.M;
+    // lane i holds coarse sample tau_a + A - 6 + i: step s interpolates from lanes s .. s + 12
+    const cplx<T> smp = b[(tau_a + (uint32_t)a.tau_off - 6u + (uint32_t)lane) & mmask];
+    cplx<T> P = mk<T>(T(1), T(0)), Q = mk<T>(T(1), T(0));
+    if (PHASOR) {
+      // carrier: exp(2 pi i kc f / Lf), f = 64 (tau + A) + lane - e: per-lane factor P, per-step factor Q (lane i
+      // holds the factor of step i); the phases are exact integers modulo Lf
+      const uint32_t kc = (uint32_t)(bd.k_lo + bd.k_len / 2);
+      double c, s;
+      unit_root((kc * (uint32_t)(lane - a.lane_off)) & lmask, a.two_over_len, &c, &s);
+      P = mk<T>((T)c, (T)s);
+      unit_root((kc * kZoomD * (tau_a + (uint32_t)a.tau_off + (uint32_t)lane)) & lmask, a.two_over_len, &c, &s);
+      Q = mk<T>((T)c, (T)s);
+    }
+    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * a.n;
+    char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+    char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    uint32_t tb = t_base;
+    asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
+    T rowacc = T(0), pl = T(0);
+    float sx[STEPS + TAPS - 1], sy[STEPS + TAPS - 1];  // wave-uniform coarse samples (scalar registers)
+#pragma unroll
+    for (int i = 0; i < TAPS - 1; ++i) {
+      sx[i] = lane_value(smp.x, i);
+      sy[i] = lane_value(smp.y, i);
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      sx[s + TAPS - 1] = lane_value(smp.x, s + TAPS - 1);
+      sy[s + TAPS - 1] = lane_value(smp.y, s + TAPS - 1);
+      T br = T(0), bi = T(0);
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        br = fmaf(wgt[j], sx[s + j], br);
+        bi = fmaf(wgt[j], sy[s + j], bi);
+      }
+      cplx<T> z = mk<T>(br, bi);
+      if (PHASOR) {
+        const cplx<T> q = mk<T>(lane_value(Q.x, s), lane_value(Q.y, s));
+        z = cmul_rn(z, cmul_rn(P, q));
+      }
+      const uint32_t tt = tb + (uint32_t)(kZoomD * s);
+      if (COEF) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+      const T m2 = norm2(z.x, z.y);
+      if (BITS) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
+      const T p = mul_rn(a.power_scale, m2);
+      colp[s] += p;
+      rowacc += p;
+      mx = p > mx ? p : mx;
+      pl += plog2p(p);
+    }
+    plogp += (double)pl;
+    if (a.part_band) {
+      const double r = wave_sum((double)rowacc);
+      if (lane == 0) a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.nblk + gw] = r;
+    }
+  }
+
+  T tot = T(0);
+  char* __restrict__ time_row = reinterpret_cast<char*>(
+      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * a.n : nullptr);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    tot += colp[s];
+    const uint32_t tt = t_base + (uint32_t)(kZoomD * s);
+    if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = colp[s];
+  }
+  if (a.part_stat) {
+    const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
+    if (lane == 0) {
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + (int64_t)blockIdx.y * gridDim.x * NW + gw) * 3;
+      o[0] = r0;
+      o[1] = r1;
+      o[2] = r2;
+    }
+  }
+}
+
+template <typename T, bool PHASOR>
+int launch_zoom_v(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+  if (coef && bits) k_zoom<T, kZoomSteps, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (coef) k_zoom<T, kZoomSteps, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (bits) k_zoom<T, kZoomSteps, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else k_zoom<T, kZoomSteps, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+}  // namespace
+
+int64_t zoom_waves(int64_t n) { return n / ((int64_t)kZoomD * kZoomSteps); }
+
+template <>
+int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+  if (a.nbands <= 0) return QI_OK;
+  dim3 grid((unsigned)ceil_div(a.M, 256), (unsigned)a.nbands, (unsigned)n_channels);
+  if (a.stx) k_zoom_gather<float, true><<<grid, 256, 0, st>>>(a);
+  else k_zoom_gather<float, false><<<grid, 256, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_zoom<float>(const ZoomArgs<float>& a, int nchunk, int64_t n_channels, hipStream_t st) {
+  if (a.nbands <= 0) return QI_OK;
+  const int64_t waves = zoom_waves(a.n);
+  if (waves * kZoomD * kZoomSteps != a.n || waves % (kZoomThreads / kWave) != 0) {
+    set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
+              kZoomD * kZoomSteps * (kZoomThreads / kWave));
+    return QI_ERR_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)(waves / (kZoomThreads / kWave)), (unsigned)nchunk, (unsigned)n_channels);
+  return a.stx ? launch_zoom_v<float, false>(a, grid, st) : launch_zoom_v<float, true>(a, grid, st);
+}
+
+// Interpolation weights of lane L for tap j: h((j - 6) - (L - e) / 64), h = 12-tap Kaiser-windowed sinc (beta = 14)
+void zoom_weights(int lane_off, float* w /*[64][kZoomTaps]*/) {
+  const double beta = 14.0, half = 6.0;
+  auto bessel_i0 = [](double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+      term *= (x / (2.0 * k)) * (x / (2.0 * k));
+      sum += term;
+      if (term < 1e-18 * sum) break;
+    }
+    return sum;
+  };
+  const double i0b = bessel_i0(beta);
+  for (int lane = 0; lane < kZoomD; ++lane) {
+    const double phi = (double)(lane - lane_off) / kZoomD;
+    for (int j = 0; j < kZoomTaps; ++j) {
+      const double x = (double)(j - 6) - phi;
+      double v = 0.0;
+      if (std::fabs(x) < half) {
+        const double r = x / half;
+        const double win = bessel_i0(beta * std::sqrt(1.0 - r * r)) / i0b;
+        const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
+        v = sinc * win;
+      }
+      w[lane * kZoomTaps + j] = (float)v;
+    }
+  }
+}
+
+}  // namespace native
+}  // namespace qi
