@@ -851,12 +851,12 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // zoom engine launch (narrow bands of the main table): its chunks come last
   const auto& zt = p->nat[kind];
   const bool zoom = zt.nzoom > 0;
-  const int64_t zwaves = zoom ? native::zoom_waves(n) : 0;
+  const int64_t zwaves = zoom ? native::zoom_groups(n) : 0;  // workgroups (4 waves each) along time
   const int64_t zM = zoom ? zt.Lf / native::kZoomD : 0;
   int znchunk = 0;
   const int chunk_z0 = chunk_total;
   if (zoom) {
-    znchunk = (int)ceil_div(p->native_zoom_waves, zwaves * C);
+    znchunk = (int)ceil_div(p->native_zoom_waves, 4 * zwaves * C);
     if (znchunk < 1) znchunk = 1;
     if (znchunk > zt.nzoom) znchunk = zt.nzoom;
     chunk_total += znchunk;
@@ -865,7 +865,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
   if (blk_slots > nbk) nbk = blk_slots;
   if (zwaves > nbk) nbk = zwaves;
-  const int64_t stat_slots = (int64_t)chunk_p2 * nbk + blk_stats + zoom_stats + (shorts ? p->nedge : 0);
+  const int64_t p2_stats = (int64_t)chunk_p2 * nblk_max;
+  const int64_t stat_slots = p2_stats + blk_stats + zoom_stats + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
@@ -960,6 +961,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       a.part_band = want_band ? part_band : nullptr;
       a.part_stat = want_stat ? part_stat : nullptr;
       a.nblk = nbk;
+      a.stat_nblk = nblk_max;
       a.stat_stride = stat_slots;
       a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
@@ -1006,7 +1008,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.part_stat = want_stat ? part_stat : nullptr;
       z.nblk = nbk;
       z.stat_stride = stat_slots;
-      z.stat_base = (int64_t)chunk_p2 * nbk + blk_stats;
+      z.stat_base = p2_stats + blk_stats;
       z.chunk_base = chunk_z0;
       z.chunk_total = chunk_total;
       z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
@@ -1033,7 +1035,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.part_stat = want_stat ? part_stat : nullptr;
       b.nblk = nbk;
       b.stat_stride = stat_slots;
-      b.stat_base = (int64_t)chunk_p2 * nbk;
+      b.stat_base = p2_stats;
       b.chunk_base = chunk_p2;
       b.chunk_total = chunk_total;
       b.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);

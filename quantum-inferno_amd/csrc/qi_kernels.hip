@@ -183,7 +183,23 @@ __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ par
   } else {
     if (!part_stat || !stats) return;
     const double* p = part_stat + c * nstat * 3;
-    for (int64_t i = tid; i < nstat; i += 256) {
+    int64_t i = tid;
+    for (; i + 3 * 256 < nstat; i += 4 * 256) {  // four independent entries in flight, summed in index order
+      double m[4], s1[4], s2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        m[u] = p[3 * (i + 256 * u)];
+        s1[u] = p[3 * (i + 256 * u) + 1];
+        s2[u] = p[3 * (i + 256 * u) + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 = m[u] > a0 ? m[u] : a0;
+        a1 += s1[u];
+        a2 += s2[u];
+      }
+    }
+    for (; i < nstat; i += 256) {
       a0 = p[3 * i] > a0 ? p[3 * i] : a0;
       a1 += p[3 * i + 1];
       a2 += p[3 * i + 2];

@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
         s1 += s_fin[1][w];
         s2 += s_fin[2][w];
       }
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.nblk + grp) * 3;
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.stat_nblk + grp) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;
@@ -570,18 +570,40 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
 }
 
 // power_time[c][t] = sum over chunks of time_part[c][q][t] (+ the corrected edge samples of the short-atom bands)
-template <typename T>
-__global__ void k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
-                              const T* __restrict__ edge_time, int64_t wmax) {
+template <typename T, int VEC>  // VEC samples per thread and plane (4: one 16-byte float load; needs aligned rows)
+__global__ void __launch_bounds__(256) k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
+                                                     const T* __restrict__ edge_time, int64_t wmax) {
+  struct alignas(sizeof(T) * VEC) Pack {
+    T v[VEC];
+  };
   const int64_t c = blockIdx.y;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-    T s = T(0);
-    for (int q = 0; q < nchunk; ++q) s += part[(c * nchunk + q) * n + t];
-    if (edge_time) {
-      if (t < wmax) s += edge_time[(c * 2 + 0) * wmax + t];
-      if (t >= n - wmax) s += edge_time[(c * 2 + 1) * wmax + (n - 1 - t)];
+  for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; t < n; t += (int64_t)gridDim.x * blockDim.x * VEC) {
+    if (t + VEC <= n) {
+      Pack s = *reinterpret_cast<const Pack*>(part + (c * nchunk) * n + t);
+      for (int q = 1; q < nchunk; ++q) {
+        const Pack x = *reinterpret_cast<const Pack*>(part + (c * nchunk + q) * n + t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s.v[i] += x.v[i];
+      }
+      if (edge_time) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          if (t + i < wmax) s.v[i] += edge_time[(c * 2 + 0) * wmax + t + i];
+          if (t + i >= n - wmax) s.v[i] += edge_time[(c * 2 + 1) * wmax + (n - 1 - t - i)];
+        }
+      }
+      *reinterpret_cast<Pack*>(out + c * n + t) = s;
+    } else {
+      for (int64_t u = t; u < n; ++u) {
+        T s = T(0);
+        for (int q = 0; q < nchunk; ++q) s += part[(c * nchunk + q) * n + u];
+        if (edge_time) {
+          if (u < wmax) s += edge_time[(c * 2 + 0) * wmax + u];
+          if (u >= n - wmax) s += edge_time[(c * 2 + 1) * wmax + (n - 1 - u)];
+        }
+        out[c * n + u] = s;
+      }
     }
-    out[c * n + t] = s;
   }
 }
 
@@ -888,8 +910,15 @@ int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, i
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                        hipStream_t st) {
-  dim3 g((unsigned)(ceil_div(n, 256) > 1024 ? 1024 : ceil_div(n, 256)), (unsigned)C);
-  k_time_reduce<T><<<g, 256, 0, st>>>(part, out, n, nchunk, edge_time, wmax);
+  const bool aligned = n % 4 == 0 && reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0 &&
+                       reinterpret_cast<uintptr_t>(part) % (4 * sizeof(T)) == 0;
+  if (aligned) {
+    dim3 g((unsigned)(ceil_div(n, 1024) > 4096 ? 4096 : ceil_div(n, 1024)), (unsigned)C);
+    k_time_reduce<T, 4><<<g, 256, 0, st>>>(part, out, n, nchunk, edge_time, wmax);
+  } else {
+    dim3 g((unsigned)(ceil_div(n, 256) > 4096 ? 4096 : ceil_div(n, 256)), (unsigned)C);
+    k_time_reduce<T, 1><<<g, 256, 0, st>>>(part, out, n, nchunk, edge_time, wmax);
+  }
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

@@ -48,7 +48,8 @@ struct RowArgs {
   T* time_part;       // [C][chunk_total][n]
   double* part_band;  // [C][panel_bands][nblk]
   double* part_stat;  // [C][chunk_total][nblk][3]
-  int64_t nblk;       // partial slots per band (stride of part_band rows and of part_stat chunks)
+  int64_t nblk;       // partial slots per band (stride of part_band rows)
+  int64_t stat_nblk;  // part_stat entries per chunk of this engine
   int64_t stat_stride;  // part_stat entries per channel
   int32_t bands_per_chunk;
   T power_scale, eps;
@@ -146,13 +147,13 @@ struct ZoomArgs {
   cplx<T>* coef;
   T* bits;
   T* time_part;       // [C][chunk_total][n]
-  double* part_band;  // [C][panel_bands][nblk]: slot = wave index along time
-  double* part_stat;  // [C][stat_stride][3]: slot = stat_base + chunk * waves + wave
+  double* part_band;  // [C][panel_bands][nblk]: slot = workgroup index along time
+  double* part_stat;  // [C][stat_stride][3]: slot = stat_base + chunk * groups + group
   int64_t nblk, stat_stride, stat_base;
   int32_t chunk_base, chunk_total;
   T power_scale, eps;
 };
-int64_t zoom_waves(int64_t n);  // waves along time (partial slots per band, stat slots per chunk)
+int64_t zoom_groups(int64_t n);  // workgroups along time (partial slots per band, stat slots per chunk)
 template <typename T>
 int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 template <typename T>

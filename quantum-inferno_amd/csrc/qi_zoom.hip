@@ -10,7 +10,7 @@
 // One wave = 64 lanes = the 64 fine positions between two coarse samples: lane L produces sample 64 tau + L for
 // kSteps consecutive tau; the coarse samples a step needs are uniform over the wave (scalar registers, taken from a
 // vector register by v_readlane), the 13 interpolation weights are per-lane constants, every store is a 512-byte
-// run.  Waves are independent: no LDS, no barriers.  No MFMA: there is no dense contraction here.
+// run.  Waves only meet for the per-band power sum (one barrier per band).  No MFMA: there is no dense contraction here.
 #include "qi_common.hpp"
 #include "qi_device.hpp"
 #include "qi_native.hpp"
@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   T mx = T(0);
   double plogp = 0.0;
   const uint32_t t_base = tau_a * kZoomD + (uint32_t)lane;  // output sample of step s: t_base + 64 s
+  __shared__ double s_red[2][NW];
+  int par = 0;  // double-buffered so that one barrier per band is enough
 
   for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
     const BandDesc bd = a.bands[jj];
@@ -131,8 +133,16 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     }
     plogp += (double)pl;
     if (a.part_band) {
+      // one partial per workgroup and band: wave sums through LDS, written by thread 0 a band later
       const double r = wave_sum((double)rowacc);
-      if (lane == 0) a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.nblk + gw] = r;
+      if (lane == 0) s_red[par][wv] = r;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < NW; ++q) t += s_red[par][q];
+        a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.nblk + blockIdx.x] = t;
+      }
+      par ^= 1;
     }
   }
 
@@ -146,12 +156,25 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = colp[s];
   }
   if (a.part_stat) {
+    __shared__ double s_fin[3][NW];
     const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
     if (lane == 0) {
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + (int64_t)blockIdx.y * gridDim.x * NW + gw) * 3;
-      o[0] = r0;
-      o[1] = r1;
-      o[2] = r2;
+      s_fin[0][wv] = r0;
+      s_fin[1][wv] = r1;
+      s_fin[2][wv] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < NW; ++q) {
+        m = s_fin[0][q] > m ? s_fin[0][q] : m;
+        s1 += s_fin[1][q];
+        s2 += s_fin[2][q];
+      }
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
     }
   }
 }
@@ -169,7 +192,7 @@ int launch_zoom_v(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-int64_t zoom_waves(int64_t n) { return n / ((int64_t)kZoomD * kZoomSteps); }
+int64_t zoom_groups(int64_t n) { return n / ((int64_t)kZoomD * kZoomSteps * (kZoomThreads / kWave)); }
 
 template <>
 int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
@@ -184,13 +207,13 @@ int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipS
 template <>
 int launch_zoom<float>(const ZoomArgs<float>& a, int nchunk, int64_t n_channels, hipStream_t st) {
   if (a.nbands <= 0) return QI_OK;
-  const int64_t waves = zoom_waves(a.n);
-  if (waves * kZoomD * kZoomSteps != a.n || waves % (kZoomThreads / kWave) != 0) {
+  const int64_t groups = zoom_groups(a.n);
+  if (groups * kZoomD * kZoomSteps * (kZoomThreads / kWave) != a.n) {
     set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
               kZoomD * kZoomSteps * (kZoomThreads / kWave));
     return QI_ERR_UNSUPPORTED;
   }
-  dim3 grid((unsigned)(waves / (kZoomThreads / kWave)), (unsigned)nchunk, (unsigned)n_channels);
+  dim3 grid((unsigned)groups, (unsigned)nchunk, (unsigned)n_channels);
   return a.stx ? launch_zoom_v<float, false>(a, grid, st) : launch_zoom_v<float, true>(a, grid, st);
 }
 

@@ -15,8 +15,8 @@ def shard(total, rank, world):
 
 
 def reduced_slots(n_channels, n_bands, n, time_dtype=torch.float32):
-    """float64 slots of one result's reduced product: power_band [C, B] f64 | stats [C, 4] f64 | power_time [C, n]
-    in the record dtype (float32 takes half a slot per sample)."""
+    """float64 slots of one result's reduced product: power_time [C, n] in the record dtype (float32 takes half a
+    slot per sample; first, so that its rows stay 16-byte aligned) | power_band [C, B] f64 | stats [C, 4] f64."""
     tbytes = n_channels * n * torch.empty((), dtype=time_dtype).element_size()
     return n_channels * n_bands + n_channels * 4 + (tbytes + 7) // 8
 
@@ -33,7 +33,7 @@ def pack_reduced(results):
             pad = ((-t.numel() * t.element_size()) % 8) // t.element_size()
             if pad:
                 t = torch.cat([t, t.new_zeros(pad)])
-            blob = torch.cat([r.power_band.reshape(-1), r.stats.reshape(-1), t.view(torch.float64)])
+            blob = torch.cat([t.view(torch.float64), r.power_band.reshape(-1), r.stats.reshape(-1)])
         parts.append(blob)
     return parts[0] if len(parts) == 1 else torch.cat(parts)
 
@@ -44,9 +44,10 @@ def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):
     for n_b, n in shapes:
         slots = reduced_slots(n_channels, n_b, n, time_dtype)
         block = flat[pos : pos + slots]
-        band = block[: n_channels * n_b].reshape(n_channels, n_b)
-        stats = block[n_channels * n_b : n_channels * (n_b + 4)].reshape(n_channels, 4)
-        time = block[n_channels * (n_b + 4) :].view(time_dtype)[: n_channels * n].reshape(n_channels, n)
+        tslots = slots - n_channels * (n_b + 4)
+        time = block[:tslots].view(time_dtype)[: n_channels * n].reshape(n_channels, n)
+        band = block[tslots : tslots + n_channels * n_b].reshape(n_channels, n_b)
+        stats = block[tslots + n_channels * n_b :].reshape(n_channels, 4)
         out.append((band, time, stats))
         pos += slots
     return out

@@ -241,10 +241,11 @@ class TfrPlan:
                 from .dist import reduced_slots
 
                 res.reduced = torch.empty(reduced_slots(n_ch, n_b, self.n, self.rdtype), dtype=torch.float64, device=dev)
-                o1, o2 = n_ch * n_b, n_ch * (n_b + 4)
-                res.power_band = res.reduced[:o1].view(n_ch, n_b)
-                res.stats = res.reduced[o1:o2].view(n_ch, 4)
-                res.power_time = res.reduced[o2:].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
+                o1 = res.reduced.numel() - n_ch * (n_b + 4)
+                o2 = o1 + n_ch * n_b
+                res.power_time = res.reduced[:o1].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
+                res.power_band = res.reduced[o1:o2].view(n_ch, n_b)
+                res.stats = res.reduced[o2:].view(n_ch, 4)
         out = _lib.TfrOut(
             coef=_lib.ptr(res.coef),
             bits=_lib.ptr(res.bits),
