@@ -226,8 +226,8 @@ struct qi_plan {
     std::vector<NativeGroup> groups;
     void* Hc = nullptr;
     void* Hfull = nullptr;
-    native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip)
-    int32_t nzoom = 0;
+    native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip), by interpolator class
+    int32_t nzoom = 0, zoom_count[3] = {0, 0, 0};
     void release() {
       if (d_zoom) (void)hipFree(d_zoom);
       if (d_bands) (void)hipFree(d_bands);
@@ -258,7 +258,7 @@ struct qi_plan {
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
-  float* d_zoom_w[2] = {nullptr, nullptr};  // interpolation weights for lane offsets 0 and 1
+  float* d_zoom_w[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // weights [class][lane offset]
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
@@ -420,24 +420,34 @@ bool native_wanted(const qi_plan* p, int kind) {
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
 int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
-  // narrow-spectrum bands go to the zoom engine: support at most 1 / kZoomOversample of the coarse grid
-  if (p->native_zoom && kind != 3 && Lf % native::kZoomD == 0 && p->n % (native::kZoomD * native::kZoomSteps * 4) == 0) {
-    const int64_t M = Lf / native::kZoomD;
+  // bands marked for the zoom engine (mode 2 + class) leave the pass-2 list, ordered by class
+  {
     std::vector<native::BandDesc> zoom, rest;
-    for (const auto& d : bands) (d.mode == 0 && d.k_len <= M / native::kZoomOversample ? zoom : rest).push_back(d);
+    for (int c = 0; c < 3; ++c) {
+      t.zoom_count[c] = 0;
+      for (const auto& d : bands)
+        if (d.mode == 2 + c) {
+          zoom.push_back(d);
+          t.zoom_count[c]++;
+        }
+    }
+    for (const auto& d : bands)
+      if (d.mode < 2) rest.push_back(d);
     if (!zoom.empty()) {
       QI_HIP(hipMalloc((void**)&t.d_zoom, zoom.size() * sizeof(native::BandDesc)));
       QI_HIP(hipMemcpy(t.d_zoom, zoom.data(), zoom.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
       t.nzoom = (int32_t)zoom.size();
-      for (int e = 0; e < 2; ++e) {
-        if (p->d_zoom_w[e]) continue;
-        std::vector<float> w((size_t)native::kZoomD * native::kZoomTaps);
-        native::zoom_weights(e, w.data());
-        QI_HIP(hipMalloc((void**)&p->d_zoom_w[e], w.size() * sizeof(float)));
-        QI_HIP(hipMemcpy(p->d_zoom_w[e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
-      }
-      bands.swap(rest);
+      for (int c = 0; c < 3; ++c)
+        for (int e = 0; e < 2; ++e) {
+          if (p->d_zoom_w[c][e]) continue;
+          const int taps = native::zoom_taps(c);
+          std::vector<float> w((size_t)native::kZoomD * taps);
+          native::zoom_weights(c, e, w.data());
+          QI_HIP(hipMalloc((void**)&p->d_zoom_w[c][e], w.size() * sizeof(float)));
+          QI_HIP(hipMemcpy(p->d_zoom_w[c][e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
+    bands.swap(rest);
   }
   if (bands.empty()) {  // every band is produced by the block / zoom engines: an empty but valid table
     t.Lf = Lf;
@@ -532,7 +542,7 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
     QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
     for (int jj = 0; jj < nbk; ++jj) {
       const native::BandDesc& d = bands[q + jj];
-      if (d.mode == 0)
+      if (d.mode != 1)
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
                                               d.k_len, circular, 1.0 / (double)L, st));
       else
@@ -685,6 +695,20 @@ int build_block_stx(qi_plan* p, const std::vector<BlockPick>& picks, const std::
   return finish_block_table<T>(p, 2, 1, picks, taps, st);
 }
 
+// Zoom engine class of a band with `len` occupied bins out of Lf (-1: not eligible): the coarse grid has M = Lf / 64
+// samples; the band is oversampled M / len times and the interpolator is sized for >= 4 (13 taps), >= 2 (19) or
+// >= 4/3 (37).
+int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
+  if (!p->native_zoom || table == 3 || len <= 0 || Lf % native::kZoomD != 0 ||
+      p->n % (native::kZoomD * native::kZoomSteps * 4) != 0)
+    return -1;
+  const int64_t M = Lf / native::kZoomD;
+  if (4 * len <= M) return 0;
+  if (2 * len <= M) return 1;
+  if (4 * len <= 3 * M) return 2;
+  return -1;
+}
+
 // Classify bands by spectrum support, allocate and fill one table.
 template <typename T>
 int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B, const std::vector<int32_t>& ids,
@@ -701,8 +725,9 @@ int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B,
     d.out_band = ids[q];
     d.edge = edge_w.empty() ? 0 : edge_w[q];
     d.edge_slot = (int32_t)q;  // the edge list is in the order of `ids`
-    if (len > 0 && len <= p->native_kmax) {
-      d.mode = 0;
+    const int zc = zoom_class(p, table, L, len);
+    if (zc >= 0 || (len > 0 && len <= p->native_kmax)) {
+      d.mode = zc >= 0 ? 2 + zc : 0;  // 0: one-pass loader of pass 2; 2 + c: zoom engine, class c
       d.k_lo = (int32_t)lo;
       d.k_len = (int32_t)len;
       d.src_off = compact;
@@ -748,7 +773,8 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
     if (can_block && block_group_of(w) > 0) {
       picks.push_back({j, block_group_of(w), 0});
-    } else if (can_short && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 && w < (double)n / 8) {
+    } else if (can_short && zoom_class(p, bank, L, len) < 0 && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 &&
+               w < (double)n / 8) {
       shorts.push_back(j);
       short_w.push_back((int32_t)w);
     } else {
@@ -853,15 +879,24 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const bool zoom = zt.nzoom > 0;
   const int64_t zwaves = zoom ? native::zoom_groups(n) : 0;  // workgroups (4 waves each) along time
   const int64_t zM = zoom ? zt.Lf / native::kZoomD : 0;
-  int znchunk = 0;
+  int znchunk[3] = {0, 0, 0}, zplanes = 0;
+  int64_t zstat_base[3] = {0, 0, 0}, zoom_stats = 0;
   const int chunk_z0 = chunk_total;
   if (zoom) {
-    znchunk = (int)ceil_div(p->native_zoom_waves, 4 * zwaves * C);
-    if (znchunk < 1) znchunk = 1;
-    if (znchunk > zt.nzoom) znchunk = zt.nzoom;
-    chunk_total += znchunk;
+    // the interpolator classes are separate launches that share their per-time planes: the launch with the most
+    // chunks runs first and writes them, the others add to them
+    for (int c = 0; c < 3; ++c) {
+      if (zt.zoom_count[c] <= 0) continue;
+      int nc = (int)ceil_div(p->native_zoom_waves, 4 * zwaves * C);
+      if (nc < 1) nc = 1;
+      if (nc > zt.zoom_count[c]) nc = zt.zoom_count[c];
+      znchunk[c] = nc;
+      if (nc > zplanes) zplanes = nc;
+      zstat_base[c] = zoom_stats;
+      zoom_stats += (int64_t)nc * zwaves;
+    }
+    chunk_total += zplanes;
   }
-  const int64_t zoom_stats = (int64_t)znchunk * zwaves;
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
   if (blk_slots > nbk) nbk = blk_slots;
   if (zwaves > nbk) nbk = zwaves;
@@ -998,7 +1033,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       // panel sample t is full-length sample t + off: linear correlation off = n/2 - 1, rolled circular n/2, Stockwell 0
       z.lane_off = kind == 0 ? 1 : 0;
       z.tau_off = kind == 2 ? 0 : n / 2 / native::kZoomD;
-      z.weights = p->d_zoom_w[z.lane_off];
       z.inv_len = (T)(1.0 / (double)zt.Lf);
       z.two_over_len = (float)(2.0 / (double)zt.Lf);
       z.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
@@ -1008,7 +1042,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.part_stat = want_stat ? part_stat : nullptr;
       z.nblk = nbk;
       z.stat_stride = stat_slots;
-      z.stat_base = p2_stats + blk_stats;
       z.chunk_base = chunk_z0;
       z.chunk_total = chunk_total;
       z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
@@ -1016,7 +1049,24 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       p->prof.begin(st, QI_STAGE_ZOOM);
       QI_TRY(native::launch_zoom_gather<T>(z, ct, st));
       QI_TRY(fft_c2c<T>(p->fft, zcoarse, zM, ct * zt.nzoom, HIPFFT_BACKWARD, st));
-      QI_TRY(native::launch_zoom<T>(z, znchunk, ct, st));
+      int order[3] = {0, 1, 2};
+      std::stable_sort(order, order + 3, [&](int x, int y) { return znchunk[x] > znchunk[y]; });
+      int first = 0;
+      bool planes_written = false;
+      for (int oi = 0; oi < 3; ++oi) {
+        const int c = order[oi];
+        if (znchunk[c] <= 0) continue;
+        first = 0;
+        for (int q = 0; q < c; ++q) first += zt.zoom_count[q];
+        native::ZoomArgs<T> zc = z;
+        zc.band_first = first;
+        zc.band_count = zt.zoom_count[c];
+        zc.weights = p->d_zoom_w[c][z.lane_off];
+        zc.stat_base = p2_stats + blk_stats + zstat_base[c];
+        zc.time_accumulate = planes_written ? 1 : 0;
+        QI_TRY(native::launch_zoom<T>(zc, c, znchunk[c], ct, st));
+        planes_written = true;
+      }
       p->prof.end(QI_STAGE_ZOOM, st);
     }
     if (blocks) {
@@ -1258,8 +1308,9 @@ int qi_plan_destroy(qi_plan* p) {
 #endif
   for (auto& t : p->nat) t.release();
   for (auto& t : p->blk) t.release();
-  for (auto* w : p->d_zoom_w)
-    if (w) (void)hipFree(w);
+  for (auto& wc : p->d_zoom_w)
+    for (auto* w : wc)
+      if (w) (void)hipFree(w);
   if (p->d_edge) (void)hipFree(p->d_edge);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
@@ -1397,8 +1448,9 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       d.coef = coef[j];
       d.out_band = j;
       const double kh = std::floor(std::sqrt(30.0) / coef[j]);
-      if (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n) {
-        d.mode = 0;
+      const int zc = 2 * kh + 1 < (double)p->n ? zoom_class(p, 2, p->n, (int64_t)(2 * kh + 1)) : -1;
+      if (zc >= 0 || (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n)) {
+        d.mode = zc >= 0 ? 2 + zc : 0;
         d.k_lo = -(int32_t)kh;
         d.k_len = 2 * (int32_t)kh + 1;
       } else {

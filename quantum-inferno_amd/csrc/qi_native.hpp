@@ -127,18 +127,21 @@ int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
 
 // ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
 constexpr int kZoomD = 64;      // fine samples per coarse sample (one wave lane per fine position)
-constexpr int kZoomTaps = 13;   // interpolation taps: 12-tap Kaiser-windowed sinc, one more for the half-open phase range
 constexpr int kZoomSteps = 16;  // coarse steps (of 64 outputs each) one wave produces per band
-constexpr int kZoomOversample = 4;  // a band qualifies if its support is at most M / kZoomOversample bins
+// interpolator classes: a band oversampled >= 4x, >= 2x, >= 4/3x on the coarse grid gets a 12-, 18-, 36-tap
+// Kaiser-windowed sinc (beta = 14; one more tap covers the half-open phase range)
+constexpr int zoom_taps(int cls) { return cls == 0 ? 13 : (cls == 1 ? 19 : 37); }
 template <typename T>
 struct ZoomArgs {
   int64_t n, Lf, M;        // M = Lf / kZoomD coarse samples per band
   int32_t nbands, panel_bands;
-  const BandDesc* bands;   // [nbands] device: one-pass ("pruned") descriptors of the zoom bands
+  const BandDesc* bands;   // [nbands] device: one-pass ("pruned") descriptors of the zoom bands, by class
+  int32_t band_first, band_count;  // the fine launch's range of `bands` (one interpolator class)
+  int32_t time_accumulate;         // add to the per-time planes instead of writing them (later launches of a call)
   const cplx<T>* X;        // [C][Lf] spectra of the records
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
   cplx<T>* coarse;         // [C][nbands][M]: baseband spectra, then (after the batched inverse FFT) coarse samples
-  const float* weights;    // [kZoomD][kZoomTaps] interpolation weights of the lanes
+  const float* weights;    // [kZoomD][taps] interpolation weights of the lanes
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
   int64_t tau_off;
@@ -157,8 +160,8 @@ int64_t zoom_groups(int64_t n);  // workgroups along time (partial slots per ban
 template <typename T>
 int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 template <typename T>
-int launch_zoom(const ZoomArgs<T>& a, int nchunk, int64_t n_channels, hipStream_t st);
-void zoom_weights(int lane_off, float* w /*[kZoomD][kZoomTaps]*/);
+int launch_zoom(const ZoomArgs<T>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st);
+void zoom_weights(int cls, int lane_off, float* w /*[kZoomD][zoom_taps(cls)]*/);
 
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,

@@ -57,9 +57,9 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
 
 // Fine stage.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands are at
 // baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
-template <typename T, int STEPS, bool PHASOR, bool COEF, bool BITS>
+template <typename T, int STEPS, int TAPS, bool PHASOR, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
-  constexpr int NW = kZoomThreads / kWave, TAPS = kZoomTaps;
+  constexpr int NW = kZoomThreads / kWave, HALF = (TAPS - 1) / 2;
   static_assert(STEPS + TAPS - 1 <= kWave, "the window of one wave must fit its lanes");
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t ch = blockIdx.z;
@@ -78,11 +78,11 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   __shared__ double s_red[2][NW];
   int par = 0;  // double-buffered so that one barrier per band is enough
 
-  for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
+  for (int jj = a.band_first + blockIdx.y; jj < a.band_first + a.band_count; jj += gridDim.y) {
     const BandDesc bd = a.bands[jj];
     const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.nbands + jj) * a.M;
-    // lane i holds coarse sample tau_a + A - 6 + i: step s interpolates from lanes s .. s + 12
-    const cplx<T> smp = b[(tau_a + (uint32_t)a.tau_off - 6u + (uint32_t)lane) & mmask];
+    // lane i holds coarse sample tau_a + A - HALF + i: step s interpolates from lanes s .. s + TAPS - 1
+    const cplx<T> smp = b[(tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask];
     cplx<T> P = mk<T>(T(1), T(0)), Q = mk<T>(T(1), T(0));
     if (PHASOR) {
       // carrier: exp(2 pi i kc f / Lf), f = 64 (tau + A) + lane - e: per-lane factor P, per-step factor Q (lane i
@@ -100,22 +100,38 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     uint32_t tb = t_base;
     asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
     T rowacc = T(0), pl = T(0);
-    float sx[STEPS + TAPS - 1], sy[STEPS + TAPS - 1];  // wave-uniform coarse samples (scalar registers)
+    // interpolation: real parts of all steps, then imaginary parts (the wave-uniform coarse samples sit in scalar
+    // registers, taken from `smp` by v_readlane as the window slides; one part at a time keeps them within budget)
+    T zr[STEPS], zi[STEPS];
+    {
+      float sx[STEPS + TAPS - 1];
 #pragma unroll
-    for (int i = 0; i < TAPS - 1; ++i) {
-      sx[i] = lane_value(smp.x, i);
-      sy[i] = lane_value(smp.y, i);
+      for (int i = 0; i < TAPS - 1; ++i) sx[i] = lane_value(smp.x, i);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        sx[s + TAPS - 1] = lane_value(smp.x, s + TAPS - 1);
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sx[s + j], acc);
+        zr[s] = acc;
+      }
+    }
+    {
+      float sy[STEPS + TAPS - 1];
+#pragma unroll
+      for (int i = 0; i < TAPS - 1; ++i) sy[i] = lane_value(smp.y, i);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        sy[s + TAPS - 1] = lane_value(smp.y, s + TAPS - 1);
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sy[s + j], acc);
+        zi[s] = acc;
+      }
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      sx[s + TAPS - 1] = lane_value(smp.x, s + TAPS - 1);
-      sy[s + TAPS - 1] = lane_value(smp.y, s + TAPS - 1);
-      T br = T(0), bi = T(0);
-#pragma unroll
-      for (int j = 0; j < TAPS; ++j) {
-        br = fmaf(wgt[j], sx[s + j], br);
-        bi = fmaf(wgt[j], sy[s + j], bi);
-      }
+      const T br = zr[s], bi = zi[s];
       cplx<T> z = mk<T>(br, bi);
       if (PHASOR) {
         const cplx<T> q = mk<T>(lane_value(Q.x, s), lane_value(Q.y, s));
@@ -153,7 +169,10 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   for (int s = 0; s < STEPS; ++s) {
     tot += colp[s];
     const uint32_t tt = t_base + (uint32_t)(kZoomD * s);
-    if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = colp[s];
+    if (time_row) {
+      T* dst = reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T)));
+      *dst = a.time_accumulate ? *dst + colp[s] : colp[s];
+    }
   }
   if (a.part_stat) {
     __shared__ double s_fin[3][NW];
@@ -179,15 +198,19 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   }
 }
 
-template <typename T, bool PHASOR>
+template <typename T, int TAPS, bool PHASOR>
 int launch_zoom_v(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
   const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
-  if (coef && bits) k_zoom<T, kZoomSteps, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (coef) k_zoom<T, kZoomSteps, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (bits) k_zoom<T, kZoomSteps, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else k_zoom<T, kZoomSteps, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
+  if (coef && bits) k_zoom<T, kZoomSteps, TAPS, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (coef) k_zoom<T, kZoomSteps, TAPS, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (bits) k_zoom<T, kZoomSteps, TAPS, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else k_zoom<T, kZoomSteps, TAPS, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;
+}
+template <typename T, int TAPS>
+int launch_zoom_t(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
+  return a.stx ? launch_zoom_v<T, TAPS, false>(a, grid, st) : launch_zoom_v<T, TAPS, true>(a, grid, st);
 }
 
 }  // namespace
@@ -205,8 +228,8 @@ int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipS
 }
 
 template <>
-int launch_zoom<float>(const ZoomArgs<float>& a, int nchunk, int64_t n_channels, hipStream_t st) {
-  if (a.nbands <= 0) return QI_OK;
+int launch_zoom<float>(const ZoomArgs<float>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st) {
+  if (a.band_count <= 0) return QI_OK;
   const int64_t groups = zoom_groups(a.n);
   if (groups * kZoomD * kZoomSteps * (kZoomThreads / kWave) != a.n) {
     set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
@@ -214,12 +237,18 @@ int launch_zoom<float>(const ZoomArgs<float>& a, int nchunk, int64_t n_channels,
     return QI_ERR_UNSUPPORTED;
   }
   dim3 grid((unsigned)groups, (unsigned)nchunk, (unsigned)n_channels);
-  return a.stx ? launch_zoom_v<float, false>(a, grid, st) : launch_zoom_v<float, true>(a, grid, st);
+  switch (cls) {
+    case 0: return launch_zoom_t<float, zoom_taps(0)>(a, grid, st);
+    case 1: return launch_zoom_t<float, zoom_taps(1)>(a, grid, st);
+    default: return launch_zoom_t<float, zoom_taps(2)>(a, grid, st);
+  }
 }
 
-// Interpolation weights of lane L for tap j: h((j - 6) - (L - e) / 64), h = 12-tap Kaiser-windowed sinc (beta = 14)
-void zoom_weights(int lane_off, float* w /*[64][kZoomTaps]*/) {
-  const double beta = 14.0, half = 6.0;
+// Interpolation weights of lane L for tap j: h((j - half) - (L - e) / 64), h = Kaiser-windowed sinc (beta = 14) of
+// 2 half taps: half = 6, 9, 18 for the classes 0, 1, 2 (errors 6e-7, 4e-7, 3e-7 of a unit tone at the band edge)
+void zoom_weights(int cls, int lane_off, float* w) {
+  const int taps = zoom_taps(cls);
+  const double beta = 14.0, half = (double)((taps - 1) / 2);
   auto bessel_i0 = [](double x) {
     double sum = 1.0, term = 1.0;
     for (int k = 1; k < 64; ++k) {
@@ -232,8 +261,8 @@ void zoom_weights(int lane_off, float* w /*[64][kZoomTaps]*/) {
   const double i0b = bessel_i0(beta);
   for (int lane = 0; lane < kZoomD; ++lane) {
     const double phi = (double)(lane - lane_off) / kZoomD;
-    for (int j = 0; j < kZoomTaps; ++j) {
-      const double x = (double)(j - 6) - phi;
+    for (int j = 0; j < taps; ++j) {
+      const double x = (double)j - half - phi;
       double v = 0.0;
       if (std::fabs(x) < half) {
         const double r = x / half;
@@ -241,7 +270,7 @@ void zoom_weights(int lane_off, float* w /*[64][kZoomTaps]*/) {
         const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
         v = sinc * win;
       }
-      w[lane * kZoomTaps + j] = (float)v;
+      w[lane * taps + j] = (float)v;
     }
   }
 }
