@@ -116,8 +116,11 @@ def main():
     plan.set_stx_bands(order, fs)
     sig = torch.from_numpy(synth.channels(n, fs, first, n_ch, total_ch, np.float32 if tdtype == torch.float32 else np.float64)).to(dev)
 
-    out_c = plan.cwt(sig, coef=True, reductions=True)
-    out_s = plan.stx(sig, coef=True, reductions=True)
+    # the reduced products of both transforms live in one buffer: the message of the gather, no packing copy
+    slots = qdist.reduced_slots(n_ch, n_b, n, tdtype)
+    message = torch.empty(2 * slots, dtype=torch.float64, device=dev)
+    out_c = plan.cwt(sig, coef=True, reductions=True, reduced_out=message[:slots])
+    out_s = plan.stx(sig, coef=True, reductions=True, reduced_out=message[slots:])
 
     def step():
         plan.cwt(sig, out=out_c)
@@ -140,8 +143,9 @@ def main():
     torch.cuda.synchronize()
     stage_all = plan.profile_read()
     dominant = max(stage_all.items(), key=lambda kv: kv[1][0])[0]
-    # timed region: events around the dominant stage's launches only (every event is a bubble in the stream)
-    plan.profile(True, stages=[dominant])
+    # timed region: HIP events around the dominant stage's launches only, on every 7th transform call (odd, so that the CWT and the
+    # Stockwell calls of a step are sampled alike) -- every event is a bubble in the stream
+    plan.profile(True, stages=[dominant], period=7)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,7 +168,7 @@ def main():
         # fused inverse-FFT row pass + epilogue; hipFFT engine: the batched inverse transform)
         name, (ms, launches) = dominant, stage[dominant]
         per_launch_ms = ms / max(launches, 1)
-        launches_per_step = max(launches / args.steps, 1)
+        launches_per_step = max(stage_all[dominant][1] / 3, 1)  # spans of that stage per step
         # algorithmic bytes of that stage: the complex coefficients of the bands it produces, written once (SURVEY s8d:
         # C*B*n*s_c), plus the per-time / per-band marginals it leaves behind
         sb = plan.stage_bands(name)

@@ -133,9 +133,10 @@ typedef enum {
   QI_STAGE_ZOOM = 7,     /* native engine: narrow-band panels by coarse inverse transform + interpolation       */
   QI_STAGE_COUNT = 8
 } qi_stage;
-/* enable: 0 off, 1 every stage, otherwise a mask with bit (stage + 1) set for each stage to time (every recorded
- * event is a small bubble in the stream, so a caller that wants one stage asks for that one).  Enabling or
- * disabling also clears the counters. */
+/* enable: 0 off; low 16 bits: 1 every stage, otherwise a mask with bit (stage + 1) set for each stage to time (every
+ * recorded event is a small bubble in the stream, so a caller that wants one stage asks for that one); high 16 bits:
+ * sampling period P (0 or 1: every transform call; P: every P-th call of qi_cwt / qi_stx is timed, the others run
+ * without events).  Enabling or disabling also clears the counters. */
 int qi_plan_profile(qi_plan* plan, int enable);
 /* Sum of elapsed milliseconds and number of launches per stage since the last read; waits for the
  * recorded events.  Arrays of QI_STAGE_COUNT entries. */

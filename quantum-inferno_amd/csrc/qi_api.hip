@@ -147,10 +147,17 @@ struct Profiler {
     used.push_back(e);
     return (int)used.size() - 1;
   }
-  void unchain() { last = -1; }
+  int period = 1;      // time every period-th transform call only (the others run without any event)
+  int64_t tick = 0;
+  bool sampled = true;
+  void unchain() {  // called at every transform entry point
+    last = -1;
+    sampled = period <= 1 || tick % period == 0;
+    ++tick;
+  }
   void begin(hipStream_t st, int stage) {
     cur = -1;
-    if (!on || !((mask >> stage) & 1u)) {
+    if (!on || !sampled || !((mask >> stage) & 1u)) {
       last = -1;
       return;
     }
@@ -259,6 +266,7 @@ struct qi_plan {
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
   float* d_zoom_w[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // weights [class][lane offset]
+  int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
@@ -433,6 +441,11 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
     }
     for (const auto& d : bands)
       if (d.mode < 2) rest.push_back(d);
+    // a handful of class-1 bands is cheaper as part of the class-2 launch (longer interpolator, one launch less)
+    if (t.zoom_count[1] > 0 && t.zoom_count[1] < 6 && t.zoom_count[2] > 0) {
+      t.zoom_count[2] += t.zoom_count[1];
+      t.zoom_count[1] = 0;
+    }
     if (!zoom.empty()) {
       QI_HIP(hipMalloc((void**)&t.d_zoom, zoom.size() * sizeof(native::BandDesc)));
       QI_HIP(hipMemcpy(t.d_zoom, zoom.data(), zoom.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
@@ -560,6 +573,9 @@ struct BlockPick {
   int32_t band;   // panel row
   int wq;         // reach group: taps within 256 * wq samples (1, 2 or 4)
   int64_t shift;  // Stockwell shift index (0 for Gabor banks)
+  // analytic Gaussian filter spectrum (0: read the table row): weight(k) = amp exp2(-(cw (k - kappa))^2)
+  int analytic = 0;
+  double kappa = 0.0, cw = 0.0, amp = 0.0;
 };
 int block_group_of(double reach) { return reach <= 256.0 ? 1 : (reach <= 512.0 ? 2 : (reach <= 1024.0 ? 4 : 0)); }
 
@@ -573,6 +589,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   if (picks.empty()) return QI_OK;
   const int32_t rows = (int32_t)picks.size();
   QI_TRY(fft_c2c<double>(p->fft, taps, native::kBlk, rows, HIPFFT_FORWARD, st));
+  if (!demod) QI_TRY(native::launch_block_rotate_rows(taps, rows, st));
   QI_HIP(hipMalloc(&bt.bank, (size_t)rows * native::kBlk * sizeof(cplx<T>)));
   QI_TRY(launch_bank_convert<T>(taps, static_cast<cplx<T>*>(bt.bank), (int64_t)rows * native::kBlk, 0,
                                 1.0 / (double)native::kBlk, st));
@@ -590,6 +607,11 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       b.out_band = picks[r].band;
       b.bank_row = r;
       b.shift = (int32_t)picks[r].shift;
+      b.analytic = p->native_blk_analytic ? picks[r].analytic : 0;
+      b.kappa_int = (int32_t)std::floor(picks[r].kappa);
+      b.kappa_frac = (float)(picks[r].kappa - std::floor(picks[r].kappa));
+      b.cw = (float)picks[r].cw;
+      b.amp = (float)picks[r].amp;
       for (int k = 0; k < 4; ++k) {
         // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
         const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
@@ -772,7 +794,17 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30
     const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
     if (can_block && block_group_of(w) > 0) {
-      picks.push_back({j, block_group_of(w), 0});
+      BlockPick pk{j, block_group_of(w), 0};
+      const double p_re = h_par[j], p_im = h_par[B + j], om = h_par[2 * B + j], am = h_par[3 * B + j];
+      // a pure Gabor atom at least 2.75 samples wide (no alias of its Gaussian spectrum above 1e-16) with its centre
+      // frequency inside (0, pi): its 4096-point filter spectrum is amp sqrt(pi / p) exp(-d^2 / 4p) exp(-i theta / 2)
+      if (p_im == 0.0 && p_re > 0.0 && p_re <= 1.0 / (2.0 * 2.75 * 2.75) && om > 0.0 && om < M_PI) {
+        pk.analytic = 1;
+        pk.kappa = om * (double)native::kBlk / (2.0 * M_PI);
+        pk.cw = (2.0 * M_PI / (double)native::kBlk) * std::sqrt(M_LOG2E / (4.0 * p_re));
+        pk.amp = am * std::sqrt(M_PI / p_re) / (double)native::kBlk;
+      }
+      picks.push_back(pk);
     } else if (can_short && zoom_class(p, bank, L, len) < 0 && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 &&
                w < (double)n / 8) {
       shorts.push_back(j);
@@ -1247,6 +1279,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
+  if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -1438,7 +1471,13 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       // within sqrt(60 ln 2) sigma); it is only that short if the frequency window has decayed before Nyquist
       const double reach = std::ceil(std::sqrt(60.0 * M_LN2) * sigma[j]) + 1.0;
       if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0) {
-        picks.push_back({j, block_group_of(reach), shift_index[j]});
+        BlockPick pk{j, block_group_of(reach), shift_index[j]};
+        // the band's filter spectrum is the Gaussian window itself, centred on the band's shift index
+        pk.analytic = 1;
+        pk.kappa = (double)shift_index[j] * (double)native::kBlk / (double)p->n;
+        pk.cw = (2.0 * M_PI / (double)native::kBlk) * sigma[j] * std::sqrt(M_LOG2E / 2.0);
+        pk.amp = 1.0 / (double)native::kBlk;
+        picks.push_back(pk);
         continue;
       }
       bands.emplace_back();
@@ -1493,7 +1532,9 @@ int qi_plan_profile(qi_plan* p, int enable) {
   int64_t c[Profiler::kStages];
   p->prof.read(ms, c);
   p->prof.on = enable != 0;
-  p->prof.mask = enable == 1 ? ~0u : (uint32_t)enable >> 1;
+  p->prof.mask = (enable & 0xFFFF) == 1 ? ~0u : (uint32_t)(enable & 0xFFFF) >> 1;
+  p->prof.period = (enable >> 16) > 0 ? (enable >> 16) : 1;
+  p->prof.tick = 0;
   return QI_OK;
 }
 

@@ -61,6 +61,12 @@ __device__ __forceinline__ void half_swap(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
+// S[c] *= r0 * exp(-i pi c / 16), c = 0..15 (the second factor is a compile-time constant: W_64^(-2c))
+template <typename T, int... Cs>
+__device__ __forceinline__ void rotate_rows16(cplx<T> (&S)[16], cplx<T> r0, std::integer_sequence<int, Cs...>) {
+  ((S[Cs] = mul_tw64<T, 2 * Cs, -1>(cmul(S[Cs], r0))), ...);
+}
+
 // v[brev(q)] *= w^q, q = 1..15, powers by products of w, w^2, w^4, w^8 (depth <= 4 roundings)
 template <typename T>
 __device__ __forceinline__ void mul_powers16(cplx<T> (&v)[16], cplx<T> w) {
@@ -164,6 +170,14 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
     for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
 #pragma unroll
     for (int c = 0; c < 16; ++c) S[c] = t[c];
+    if (!DEMOD) {
+      // Gabor banks: the half-sample offset of the atoms (styx_cwt.py:113-144) is the factor exp(-i theta_k / 2) of
+      // every filter spectrum; it goes into the block spectrum once, which leaves REAL Gaussian weights per band
+      float sn, cs;
+      sincospif(-(float)col * (1.0f / (float)kBlk), &sn, &cs);
+      const cplx<T> r0 = mk<T>((T)cs, (T)sn);
+      rotate_rows16<T>(S, r0, std::make_integer_sequence<int, 16>{});
+    }
   }
 
   QI_BSTAMP(0);
@@ -183,7 +197,25 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
     const BlockBand bd = bd_next;
     if (jj + 1 < it.band_count) bd_next = a.bands[it.band_first + jj + 1];
     cplx<T> v[16];
-    {
+    if (bd.analytic) {
+      // Gaussian filter spectrum in registers: no table traffic (the table rows cost as much L2 bandwidth as the
+      // panel costs HBM bandwidth)
+      QI_BSTAMP(1);
+      QI_BSTAMP(2);
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        T dk = (T)(col + 256 * b - bd.kappa_int) - (T)bd.kappa_frac;
+        T amp = (T)bd.amp;
+        if (dk > (T)(kBlk / 2)) {
+          dk -= (T)kBlk;
+          if (!DEMOD) amp = -amp;  // half-integer sample grid: the aliases alternate in sign
+        }
+        if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
+        const T e = (T)bd.cw * dk;
+        const T r = amp * fast_exp2(-e * e);
+        v[b] = mk<T>(S[b].x * r, S[b].y * r);
+      }
+    } else {
       const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + col;
       cplx<T> h[16];
 #pragma unroll
@@ -405,6 +437,18 @@ __global__ void k_stx_window_row(double2* __restrict__ row, int64_t n, double co
   }
 }
 
+// rows[r][k] *= exp(+i pi k / kBlk): the table rows of a Gabor bank, made to match the block spectrum that carries
+// the factor exp(-i pi k / kBlk) (see block_item)
+__global__ void k_block_rotate_rows(double2* __restrict__ rows) {
+  double2* row = rows + (int64_t)blockIdx.y * kBlk;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < kBlk; k += gridDim.x * blockDim.x) {
+    double s, c;
+    sincospi((double)k / (double)kBlk, &s, &c);
+    const double2 v = row[k];
+    row[k] = make_double2(v.x * c - v.y * s, v.x * s + v.y * c);
+  }
+}
+
 template <typename T, bool DEMOD>
 int launch_block_v(const BlockArgs<T>& a, dim3 grid, hipStream_t st) {
   const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
@@ -437,6 +481,13 @@ int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total
 
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st) {
   k_block_taps_stx<<<4, 256, 0, st>>>(g, w, om, n, idx);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+int launch_block_rotate_rows(double2* rows, int count, hipStream_t st) {
+  if (count <= 0) return QI_OK;
+  k_block_rotate_rows<<<dim3(4, (unsigned)count), 256, 0, st>>>(rows);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

@@ -41,6 +41,9 @@ __device__ __forceinline__ float log2_t(float v) { return log2f(v); }
 __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 __device__ __forceinline__ float sqrt_t(float v) { return sqrtf(v); }
 __device__ __forceinline__ double sqrt_t(double v) { return sqrt(v); }
+// v_exp_f32 without the denormal-range fix-up of exp2f (results below 2^-126 are not needed where this is used)
+__device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+__device__ __forceinline__ double fast_exp2(double v) { return exp2(v); }
 __device__ __forceinline__ float exp2_t(float v) { return exp2f(v); }
 __device__ __forceinline__ double exp2_t(double v) { return exp2(v); }
 

@@ -87,8 +87,11 @@ struct BlockBand {
   int32_t out_band;  // row of the panel
   int32_t bank_row;  // row of the [rows][kBlk] filter-spectrum table
   int32_t shift;     // Stockwell: shift index idx_j (outputs are multiplied by exp(-2 pi i idx t / n))
-  int32_t pad_;
+  int32_t analytic;  // the filter spectrum is a Gaussian evaluated in registers (no table row is read)
   float rot[8];      // Stockwell: r^(2^k), k = 0..3, r = exp(-2 pi i idx 256 / n)
+  // analytic filter: weight(k) = amp * exp2(-(cw * dk)^2), dk = k - (kappa_int + kappa_frac) wrapped to +-kBlk / 2
+  int32_t kappa_int;
+  float kappa_frac, cw, amp;
 };
 struct BlockItem {  // one workgroup of the block launch
   int32_t wq;          // reach group: taps within 256 * wq samples
@@ -124,6 +127,7 @@ int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total
                             hipStream_t st);
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);
 int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
+int launch_block_rotate_rows(double2* rows, int count, hipStream_t st);
 
 // ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
 constexpr int kZoomD = 64;      // fine samples per coarse sample (one wave lane per fine position)

@@ -35,7 +35,18 @@ def pack_reduced(results):
                 t = torch.cat([t, t.new_zeros(pad)])
             blob = torch.cat([t.view(torch.float64), r.power_band.reshape(-1), r.stats.reshape(-1)])
         parts.append(blob)
-    return parts[0] if len(parts) == 1 else torch.cat(parts)
+    if len(parts) == 1:
+        return parts[0]
+    # results whose buffers were carved out of one allocation, in order (TfrPlan ..., reduced_out=): no copy at all
+    joined = all(
+        a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.storage_offset() + a.numel() == b.storage_offset()
+        for a, b in zip(parts, parts[1:])
+    )
+    if joined:
+        total = sum(p.numel() for p in parts)
+        return torch.empty(0, dtype=parts[0].dtype, device=parts[0].device).set_(
+            parts[0].untyped_storage(), parts[0].storage_offset(), (total,), (1,))
+    return torch.cat(parts)
 
 
 def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):

@@ -191,14 +191,17 @@ class TfrPlan:
 
     # -- transforms ---------------------------------------------------------------------------
     # -- measurement --------------------------------------------------------------------------
-    def profile(self, enable=True, stages=None):
+    def profile(self, enable=True, stages=None, period=1):
         """Time stage launches with HIP events on the current stream (qi_plan_profile): every stage, or only the
-        named ones (`stages`, names from `_lib.STAGES`) -- each recorded event is a small bubble in the stream."""
+        named ones (`stages`, names from `_lib.STAGES`), on every transform call or every `period`-th one -- each
+        recorded event is a small bubble in the stream."""
         code = 1 if enable else 0
         if enable and stages is not None:
             code = 0
             for name in stages:
                 code |= 1 << (_lib.STAGES.index(name) + 1)
+        if enable and period > 1:
+            code |= int(period) << 16
         _lib.check(self._lib.qi_plan_profile(self._handle, code))
 
     def stage_bands(self, stage):
@@ -213,7 +216,7 @@ class TfrPlan:
         _lib.check(self._lib.qi_plan_profile_read(self._handle, ms, cnt, len(_lib.STAGES)))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.STAGES)}
 
-    def _run(self, which, sig, coef, bits, reductions, power_scale, eps, out=None):
+    def _run(self, which, sig, coef, bits, reductions, power_scale, eps, out=None, reduced_out=None):
         if sig.dtype != self.rdtype or not sig.is_cuda or sig.device != self.device:
             sig = sig.to(device=self.device, dtype=self.rdtype)
         sig = sig.contiguous()
@@ -240,7 +243,13 @@ class TfrPlan:
                 # are views into it
                 from .dist import reduced_slots
 
-                res.reduced = torch.empty(reduced_slots(n_ch, n_b, self.n, self.rdtype), dtype=torch.float64, device=dev)
+                slots = reduced_slots(n_ch, n_b, self.n, self.rdtype)
+                if reduced_out is not None:  # caller-provided slice (e.g. of one buffer for several transforms)
+                    if reduced_out.dtype != torch.float64 or reduced_out.numel() != slots or not reduced_out.is_contiguous():
+                        raise ValueError(f"reduced_out must be a contiguous float64 tensor of {slots} elements")
+                    res.reduced = reduced_out
+                else:
+                    res.reduced = torch.empty(slots, dtype=torch.float64, device=dev)
                 o1 = res.reduced.numel() - n_ch * (n_b + 4)
                 o2 = o1 + n_ch * n_b
                 res.power_time = res.reduced[:o1].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
@@ -263,14 +272,14 @@ class TfrPlan:
         _lib.check(rc)
         return res
 
-    def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
-        return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps, out)
+    def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
+        return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps, out, reduced_out)
 
-    def cwt_atoms(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
-        return self._run(_lib.QI_BANK_ATOMS, sig, coef, bits, reductions, power_scale, eps, out)
+    def cwt_atoms(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
+        return self._run(_lib.QI_BANK_ATOMS, sig, coef, bits, reductions, power_scale, eps, out, reduced_out)
 
-    def stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None):
-        return self._run(_lib.QI_TABLE_STX, sig, coef, bits, reductions, power_scale, eps, out)
+    def stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
+        return self._run(_lib.QI_TABLE_STX, sig, coef, bits, reductions, power_scale, eps, out, reduced_out)
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
