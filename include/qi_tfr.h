@@ -130,8 +130,9 @@ typedef enum {
   QI_STAGE_PASS2 = 5,    /* native engine: second FFT pass + fused epilogue                      */
   QI_STAGE_BLOCK = 6,    /* native engine: short-atom bands by overlap-save blocks (forward, filter, inverse,  */
                          /* epilogue in one kernel)                                                             */
-  QI_STAGE_ZOOM = 7,     /* native engine: narrow-band panels by coarse inverse transform + interpolation       */
-  QI_STAGE_COUNT = 8
+  QI_STAGE_ZOOM = 7,     /* native engine: narrow-band panels, interpolation kernel (one span per launch)       */
+  QI_STAGE_ZOOM_COARSE = 8, /* native engine: baseband gather + batched coarse inverse FFT of the zoom bands     */
+  QI_STAGE_COUNT = 9
 } qi_stage;
 /* enable: 0 off; low 16 bits: 1 every stage, otherwise a mask with bit (stage + 1) set for each stage to time (every
  * recorded event is a small bubble in the stream, so a caller that wants one stage asks for that one); high 16 bits:

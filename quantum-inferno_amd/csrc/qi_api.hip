@@ -155,6 +155,7 @@ struct Profiler {
     sampled = period <= 1 || tick % period == 0;
     ++tick;
   }
+  void unchain_span() { last = -1; }  // the next span is on another stream: do not share an event with it
   void begin(hipStream_t st, int stage) {
     cur = -1;
     if (!on || !sampled || !((mask >> stage) & 1u)) {
@@ -266,6 +267,11 @@ struct qi_plan {
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
   float* d_zoom_w[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // weights [class][lane offset]
+  // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
+  // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
+  int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
@@ -976,8 +982,52 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
   cplx<T>* zcoarse = e_zc ? reinterpret_cast<cplx<T>*>(carve(e_zc)) : nullptr;
 
+  const bool overlap = blocks && p->native_overlap;
+  if (overlap && !p->side) {
+    QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  }
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
+    auto launch_blocks = [&](hipStream_t bs) -> int {
+      native::BlockArgs<T> b{};
+      b.n = n;
+      b.nitems = bt.nitems;
+      b.panel_bands = (int32_t)B;
+      b.items = bt.d_items;
+      b.bands = bt.d_bands;
+      b.bank = static_cast<const cplx<T>*>(bt.bank);
+      b.sig = sig + c0 * n;
+      b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+      b.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+      b.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+      b.part_band = want_band ? part_band : nullptr;
+      b.part_stat = want_stat ? part_stat : nullptr;
+      b.nblk = nbk;
+      b.stat_stride = stat_slots;
+      b.stat_base = p2_stats;
+      b.chunk_base = chunk_p2;
+      b.chunk_total = chunk_total;
+      b.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+      b.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+      b.two_over_n = (float)(2.0 / (double)n);
+      b.debug = p->native_debug;
+      b.stamps = p->blk_stamps;
+      p->prof.unchain_span();
+      p->prof.begin(bs, QI_STAGE_BLOCK);
+      QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
+      p->prof.end(QI_STAGE_BLOCK, bs);
+      p->prof.unchain_span();
+      return QI_OK;
+    };
+    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
+    if (overlap) {  // fork: the block launch follows the clearing of the partials and nothing else
+      QI_HIP(hipEventRecord(p->ev_fork, st));
+      QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      QI_TRY(launch_blocks(p->side));
+      QI_HIP(hipEventRecord(p->ev_join, p->side));
+    }
     p->prof.begin(st, QI_STAGE_FORWARD);
     if (p->native_fwd) {
       native::RowArgs<T> f{};
@@ -996,7 +1046,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(fft_c2c<T>(p->fft, X, Lf0, ct, HIPFFT_FORWARD, st));
     }
     if (shorts) QI_TRY(native::launch_even_bins<T>(X, Xn, ct, n, st));
-    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.end(QI_STAGE_FORWARD, st);
     int chunk_base = 0;
     for (size_t si = 0; si < subs.size(); ++si) {
@@ -1078,9 +1127,10 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.chunk_total = chunk_total;
       z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
-      p->prof.begin(st, QI_STAGE_ZOOM);
+      p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
       QI_TRY(native::launch_zoom_gather<T>(z, ct, st));
       QI_TRY(fft_c2c<T>(p->fft, zcoarse, zM, ct * zt.nzoom, HIPFFT_BACKWARD, st));
+      p->prof.end(QI_STAGE_ZOOM_COARSE, st);
       int order[3] = {0, 1, 2};
       std::stable_sort(order, order + 3, [&](int x, int y) { return znchunk[x] > znchunk[y]; });
       int first = 0;
@@ -1096,39 +1146,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         zc.weights = p->d_zoom_w[c][z.lane_off];
         zc.stat_base = p2_stats + blk_stats + zstat_base[c];
         zc.time_accumulate = planes_written ? 1 : 0;
+        p->prof.begin(st, QI_STAGE_ZOOM);
         QI_TRY(native::launch_zoom<T>(zc, c, znchunk[c], ct, st));
+        p->prof.end(QI_STAGE_ZOOM, st);
         planes_written = true;
       }
-      p->prof.end(QI_STAGE_ZOOM, st);
     }
-    if (blocks) {
-      native::BlockArgs<T> b{};
-      b.n = n;
-      b.nitems = bt.nitems;
-      b.panel_bands = (int32_t)B;
-      b.items = bt.d_items;
-      b.bands = bt.d_bands;
-      b.bank = static_cast<const cplx<T>*>(bt.bank);
-      b.sig = sig + c0 * n;
-      b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
-      b.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
-      b.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
-      b.part_band = want_band ? part_band : nullptr;
-      b.part_stat = want_stat ? part_stat : nullptr;
-      b.nblk = nbk;
-      b.stat_stride = stat_slots;
-      b.stat_base = p2_stats;
-      b.chunk_base = chunk_p2;
-      b.chunk_total = chunk_total;
-      b.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
-      b.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
-      b.two_over_n = (float)(2.0 / (double)n);
-      b.debug = p->native_debug;
-      b.stamps = p->blk_stamps;
-      p->prof.begin(st, QI_STAGE_BLOCK);
-      QI_TRY(native::launch_block<T>(b, bt.demod, ct, st));
-      p->prof.end(QI_STAGE_BLOCK, st);
-    }
+    if (blocks && !overlap) QI_TRY(launch_blocks(st));
+    if (overlap) QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));  // join before the reductions are finalised
     p->prof.begin(st, QI_STAGE_EPILOGUE);
     if (shorts) {
       native::EdgeArgs<T> e{};
@@ -1280,6 +1305,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -1341,6 +1367,9 @@ int qi_plan_destroy(qi_plan* p) {
 #endif
   for (auto& t : p->nat) t.release();
   for (auto& t : p->blk) t.release();
+  if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)
       if (w) (void)hipFree(w);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HBM bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/traffic.sh).
 gfx950 correction (MI355X_MICROARCH.md, HBM): counters are in KiB; FETCH_SIZE tallies 128-B requests at 64 B,
-so reads are doubled; WRITE_SIZE is taken as is.  Prints a table and, with --json KEY, the pass-2 figure."""
+so reads are doubled; WRITE_SIZE is taken as is.  Prints a table and, with --json KEY PREFIX, the mean bytes per launch of the kernels named PREFIX*."""
 import collections
 import csv
 import glob
@@ -30,9 +30,9 @@ def main():
         wr = 1024.0 * sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [0])), 1)
         rows[k] = (rd, wr, len(cs.get("WRITE_SIZE", [])))
         print(f"{k[:100]:100s} read {rd/1e6:10.2f} MB  write {wr/1e6:10.2f} MB  launches {rows[k][2]}")
-    if "--json" in sys.argv:
-        key = sys.argv[sys.argv.index("--json") + 1]
-        sel = [v for k, v in rows.items() if k.startswith("k_rows") and ", 2, " in k]
+    if "--json" in sys.argv:  # --json KEY PREFIX: mean HBM bytes per launch over the kernels whose name starts with PREFIX
+        key, prefix = sys.argv[sys.argv.index("--json") + 1], sys.argv[sys.argv.index("--json") + 2]
+        sel = [v for k, v in rows.items() if k.startswith(prefix)]
         tot = sum((rd + wr) * n for rd, wr, n in sel) / max(sum(n for _, _, n in sel), 1)
         print(json.dumps({key: int(tot)}))
 
