@@ -265,6 +265,7 @@ struct qi_plan {
   } blk[3];
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
+  int native_zoom_small = 0;    // classes of at most this many bands get one band per workgroup
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
   float* d_zoom_w[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // weights [class][lane offset]
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
@@ -927,6 +928,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       if (zt.zoom_count[c] <= 0) continue;
       int nc = (int)ceil_div(p->native_zoom_waves, 4 * zwaves * C);
       if (nc < 1) nc = 1;
+      // a class of a few bands: one band per workgroup, or its launch is a handful of long serial waves
+      if (zt.zoom_count[c] <= p->native_zoom_small && zwaves * C < 1024) nc = zt.zoom_count[c];
       if (nc > zt.zoom_count[c]) nc = zt.zoom_count[c];
       znchunk[c] = nc;
       if (nc > zplanes) zplanes = nc;
@@ -1303,6 +1306,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM_SMALL")) p->native_zoom_small = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);

@@ -145,7 +145,7 @@ struct ZoomArgs {
   const cplx<T>* X;        // [C][Lf] spectra of the records
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
   cplx<T>* coarse;         // [C][nbands][M]: baseband spectra, then (after the batched inverse FFT) coarse samples
-  const float* weights;    // [kZoomD][taps] interpolation weights of the lanes
+  const float* weights;    // [taps][kZoomD] interpolation weights of the lanes
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
   int64_t tau_off;
@@ -165,7 +165,7 @@ template <typename T>
 int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_zoom(const ZoomArgs<T>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st);
-void zoom_weights(int cls, int lane_off, float* w /*[kZoomD][zoom_taps(cls)]*/);
+void zoom_weights(int cls, int lane_off, float* w /*[zoom_taps(cls)][kZoomD]*/);
 
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,

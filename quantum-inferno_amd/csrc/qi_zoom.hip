@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   const uint32_t mmask = (uint32_t)a.M - 1u, lmask = (uint32_t)a.Lf - 1u;
   float wgt[TAPS];
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[lane * TAPS + j];
+  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[j * kZoomD + lane];  // [tap][lane]: coalesced
   T colp[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) colp[s] = T(0);
@@ -78,11 +78,21 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   __shared__ double s_red[2][NW];
   int par = 0;  // double-buffered so that one barrier per band is enough
 
-  for (int jj = a.band_first + blockIdx.y; jj < a.band_first + a.band_count; jj += gridDim.y) {
-    const BandDesc bd = a.bands[jj];
-    const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.nbands + jj) * a.M;
-    // lane i holds coarse sample tau_a + A - HALF + i: step s interpolates from lanes s .. s + TAPS - 1
-    const cplx<T> smp = b[(tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask];
+  // lane i holds coarse sample tau_a + A - HALF + i of the band: step s interpolates from lanes s .. s + TAPS - 1.
+  // The samples (and the descriptor) of the next band are requested a band ahead: two registers hide the one
+  // memory latency of the band loop.
+  const uint32_t widx = (tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask;
+  const int jj0 = a.band_first + blockIdx.y, jj_end = a.band_first + a.band_count;
+  cplx<T> smp_next = mk<T>(T(0), T(0));
+  BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.band_first];
+  if (jj0 < jj_end) smp_next = a.coarse[((int64_t)ch * a.nbands + jj0) * a.M + widx];
+  for (int jj = jj0; jj < jj_end; jj += gridDim.y) {
+    const BandDesc bd = bd_next;
+    const cplx<T> smp = smp_next;
+    if (jj + (int)gridDim.y < jj_end) {
+      bd_next = a.bands[jj + gridDim.y];
+      smp_next = a.coarse[((int64_t)ch * a.nbands + jj + gridDim.y) * a.M + widx];
+    }
     cplx<T> P = mk<T>(T(1), T(0)), Q = mk<T>(T(1), T(0));
     if (PHASOR) {
       // carrier: exp(2 pi i kc f / Lf), f = 64 (tau + A) + lane - e: per-lane factor P, per-step factor Q (lane i
@@ -270,7 +280,7 @@ void zoom_weights(int cls, int lane_off, float* w) {
         const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
         v = sinc * win;
       }
-      w[lane * taps + j] = (float)v;
+      w[j * kZoomD + lane] = (float)v;
     }
   }
 }

@@ -15,7 +15,7 @@ from conftest import relmax
 from oracle import tfr_oracle as orc
 
 import quantum_inferno_amd as qi
-from quantum_inferno_amd import cwt_atoms, engine, styx_cwt, styx_fft, styx_stx, tfr_info
+from quantum_inferno_amd import cwt_atoms, engine, scales_dyadic, styx_cwt, styx_fft, styx_stx, tfr_info
 
 pytestmark = pytest.mark.gpu
 
@@ -397,3 +397,39 @@ def test_welch_vs_reference(golden, dtype):
     assert pb.shape == (2, 257) and relmax(pb[1], 4 * g[f"welch_p_{dtype}"]) <= tol
     with pytest.raises(ValueError):
         styx_fft.welch_power_pow2(sig[:100], 1000.0, 512)
+
+
+@pytest.mark.parametrize("order,fs", [(6, 800.0), (12, 1000.0), (1, 1000.0)])
+def test_native_engines_other_band_tables(order, fs):
+    """Band tables with other populations of the three native sub-engines (zoom classes, block reach groups, two-pass)
+    than the benchmark's order 3: the native engine against the hipFFT engine on the same noise + chirp record,
+    n = 2^20, coefficients, bits and every fused reduction; per-band power also as a direct sum of the stored panel."""
+    from quantum_inferno_amd import _lib
+
+    n = 1 << 20
+    rng = np.random.default_rng(1234 + int(order))
+    x = (orc.synth_chirp(n, fs, 0, 1, np.float32) + 0.25 * rng.standard_normal(n).astype(np.float32))[None, :]
+    xt = torch.from_numpy(x).cuda()
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    ws = engine.TfrPlan.workspace_for(n, nb, np.float32, 1)
+    nat = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_NATIVE)
+    ref = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        plan.set_styx_bank(order, fs)
+        plan.set_stx_bands(order, fs)
+    for name in ("cwt", "stx"):
+        a = getattr(nat, name)(xt, coef=True, bits=True, reductions=True)
+        b = getattr(ref, name)(xt, coef=True, bits=True, reductions=True)
+        scale = float(b.coef.abs().max())
+        worst = float((a.coef - b.coef).abs().amax(dim=2).max()) / scale
+        assert worst <= 2e-5, (name, order, worst)
+        big = b.coef.abs() >= 1e-2 * scale
+        assert float((a.bits - b.bits).abs()[big].max()) <= 1e-3, (name, order)
+        assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
+        assert torch.allclose(a.power_time, b.power_time, rtol=1e-3, atol=1e-6 * float(b.power_time.max()))
+        assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
+        direct = (a.coef.abs().double() ** 2).sum(dim=2)
+        assert torch.allclose(a.power_band, direct, rtol=1e-5, atol=1e-9 * float(direct.max()))
+        del a, b
+    nat.close()
+    ref.close()
