@@ -435,6 +435,10 @@ bool native_wanted(const qi_plan* p, int kind) {
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
 int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
+  if (getenv("QI_NATIVE_VERBOSE"))
+    for (const auto& d : bands)
+      fprintf(stderr, "[qi plan] table %d (Lf = %lld) band %d: %s, support [%d, +%d)\n", kind, (long long)Lf, d.out_band,
+              d.mode == 0 ? "one-pass loader" : (d.mode == 1 ? "two-pass" : "zoom"), d.k_lo, d.k_len);
   // bands marked for the zoom engine (mode 2 + class) leave the pass-2 list, ordered by class
   {
     std::vector<native::BandDesc> zoom, rest;
@@ -564,11 +568,11 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
       const native::BandDesc& d = bands[q + jj];
       if (d.mode != 1)
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
-                                              d.k_len, circular, 1.0 / (double)L, st));
+                                              d.k_len, circular, 1.0 / (double)L, L, st));
       else
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
                                               static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.bank_row * L, 0, L, circular,
-                                              1.0 / (double)L, st));
+                                              1.0 / (double)L, L, st));
     }
     q = r;
   }

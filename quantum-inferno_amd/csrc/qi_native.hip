@@ -106,7 +106,7 @@ __device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowA
           const T w = exp2_t(-e * e) * a.inv_len;
           y[q] = mk<T>(x.x * w, x.y * w);
         } else {
-          y[q] = cmul(X[k], Hc[k - bd.k_lo]);
+          y[q] = cmul(X[(uint32_t)k & mask], Hc[k - bd.k_lo]);
         }
       }
     }
@@ -769,26 +769,40 @@ __global__ void __launch_bounds__(256) k_band_support(const double2* __restrict_
   }
   __syncthreads();
   const double cut = s_max * thr2;
-  double lo = (double)L, hi = -1.0;
+  // plain support [lo, hi], and the support of a spectrum that straddles bin 0: [lo2 - L, hi1] with hi1 the last bin
+  // above the cut in the lower half and lo2 the first one in the upper half; the shorter of the two is reported
+  double lo = (double)L, hi = -1.0, hi1 = -1.0, lo2 = (double)L;
   for (int64_t k = tid; k < L; k += 256) {
     const double p = f[k].x * f[k].x + f[k].y * f[k].y;
     if (p >= cut && p > 0.0) {
       lo = (double)k < lo ? (double)k : lo;
       hi = (double)k > hi ? (double)k : hi;
+      if (k < L / 2) hi1 = (double)k > hi1 ? (double)k : hi1;
+      else lo2 = (double)k < lo2 ? (double)k : lo2;
     }
   }
   lo = -wave_max(-lo);
   hi = wave_max(hi);
-  __shared__ double s_lo[256 / kWave], s_hi[256 / kWave];
+  hi1 = wave_max(hi1);
+  lo2 = -wave_max(-lo2);
+  __shared__ double s_lo[256 / kWave], s_hi[256 / kWave], s_hi1[256 / kWave], s_lo2[256 / kWave];
   if (lane == 0) {
     s_lo[wv] = lo;
     s_hi[wv] = hi;
+    s_hi1[wv] = hi1;
+    s_lo2[wv] = lo2;
   }
   __syncthreads();
   if (tid == 0) {
     for (int w = 0; w < 256 / kWave; ++w) {
       lo = s_lo[w] < lo ? s_lo[w] : lo;
       hi = s_hi[w] > hi ? s_hi[w] : hi;
+      hi1 = s_hi1[w] > hi1 ? s_hi1[w] : hi1;
+      lo2 = s_lo2[w] < lo2 ? s_lo2[w] : lo2;
+    }
+    if (hi1 >= 0.0 && lo2 < (double)L && (hi1 + 1.0) + ((double)L - lo2) < hi - lo + 1.0) {
+      lo = lo2 - (double)L;  // negative: bins are taken modulo L
+      hi = hi1;
     }
     out[blockIdx.x * 3 + 0] = s_max;
     out[blockIdx.x * 3 + 1] = lo;
@@ -799,10 +813,13 @@ __global__ void __launch_bounds__(256) k_band_support(const double2* __restrict_
 // copy a window of a float64 spectrum row into working precision, scaled (and conjugated for the circular bank)
 template <typename T>
 __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict__ dst, int64_t k_lo, int64_t count,
-                              int conj, double scale) {
+                              int conj, double scale, int64_t row_len) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const double2 v = F[k_lo + i];
+  int64_t k = k_lo + i;  // the window may start at a negative bin: bins are taken modulo the row length
+  if (k < 0) k += row_len;
+  if (k >= row_len) k -= row_len;
+  const double2 v = F[k];
   dst[i] = mk<T>((T)(v.x * scale), (T)((conj ? -v.y : v.y) * scale));
 }
 
@@ -958,13 +975,13 @@ int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double
 
 template <typename T>
 int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
-                       hipStream_t st) {
-  k_copy_window<T><<<(unsigned)ceil_div(count, 256), 256, 0, st>>>(F, dst, k_lo, count, conj, scale);
+                       int64_t row_len, hipStream_t st) {
+  k_copy_window<T><<<(unsigned)ceil_div(count, 256), 256, 0, st>>>(F, dst, k_lo, count, conj, scale, row_len);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
-template int launch_copy_window<float>(const double2*, float2*, int64_t, int64_t, int, double, hipStream_t);
-template int launch_copy_window<double>(const double2*, double2*, int64_t, int64_t, int, double, hipStream_t);
+template int launch_copy_window<float>(const double2*, float2*, int64_t, int64_t, int, double, int64_t, hipStream_t);
+template int launch_copy_window<double>(const double2*, double2*, int64_t, int64_t, int, double, int64_t, hipStream_t);
 
 }  // namespace native
 }  // namespace qi

@@ -178,7 +178,7 @@ int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st);
 template <typename T>
 int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
-                       hipStream_t st);
+                       int64_t row_len, hipStream_t st);
 
 }  // namespace native
 }  // namespace qi

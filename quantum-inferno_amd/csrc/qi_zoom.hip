@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
       const T w = exp2_t(-e * e) * a.inv_len;
       y = mk<T>(x.x * w, x.y * w);
     } else {
-      y = cmul(X[k], a.Hc[bd.src_off + (k - bd.k_lo)]);
+      y = cmul(X[(uint32_t)k & ((uint32_t)a.Lf - 1u)], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
     }
   }
   a.coarse[((int64_t)ch * a.nbands + j) * a.M + kappa] = y;
