@@ -323,8 +323,12 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   const uint32_t row0 = blockIdx.x * C::G;
   const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;  // lanes run over the G rows
   fill_step_twiddles<T, C>(tw);
+  // with phase_split the decimation-in-frequency phases of a 2048-point pass are separate workgroups (blockIdx.y =
+  // band * NPH + phase): twice the workgroups for launches that would not cover the chip
+  const int split = (NPH > 1 && a.phase_split) ? NPH : 1;
+  const int ph_first = split > 1 ? (int)(blockIdx.y % NPH) : 0, ph_last = split > 1 ? ph_first + 1 : NPH;
   BandDesc bd{};
-  if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y]];
+  if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y / split]];
   const cplx<T>* Xc = SRC == 2 ? nullptr : a.X + ch * a.Lf;
   const T* sigc = SRC == 2 ? a.sig + ch * a.n : nullptr;
   const uint32_t mask = (uint32_t)a.Lf - 1u;
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
-  for (int ph = 0; ph < NPH; ++ph) {
+  for (int ph = ph_first; ph < ph_last; ++ph) {
     if (!QI_DBG(2)) load_full<T, C, SRC, NPH>(buf, a, bd, Xc, sigc, row0, ph);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -857,8 +861,10 @@ static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
 }
 
 template <class C>
-static int launch_pass1_cfg(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
-  dim3 grid((unsigned)(a.N2 / C::G), (unsigned)a.ngen_launch, (unsigned)n_channels);
+static int launch_pass1_cfg(const RowArgs<float>& a0, int kind, int64_t n_channels, hipStream_t st) {
+  RowArgs<float> a = a0;
+  a.phase_split = a.N1 == 2048 && (a.N2 / C::G) * a.ngen_launch * n_channels < 256 ? 1 : 0;
+  dim3 grid((unsigned)(a.N2 / C::G), (unsigned)(a.ngen_launch * (a.phase_split ? 2 : 1)), (unsigned)n_channels);
   const bool stx = kind == 2;
   if (a.N1 == 1024) return stx ? launch_p1<float, C, 1, 1>(a, grid, st) : launch_p1<float, C, 0, 1>(a, grid, st);
   if (a.N1 == 2048) return stx ? launch_p1<float, C, 1, 2>(a, grid, st) : launch_p1<float, C, 0, 2>(a, grid, st);
@@ -874,9 +880,11 @@ int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, h
 
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
 template <class C1>
-static int launch_forward_cfg(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
+static int launch_forward_cfg(const RowArgs<float>& a0, float2* Xout, int64_t n_channels, hipStream_t st) {
   using C2 = C1;
-  dim3 g1((unsigned)(a.N2 / C1::G), 1, (unsigned)n_channels);
+  RowArgs<float> a = a0;
+  a.phase_split = a.N1 == 2048 && (a.N2 / C1::G) * n_channels < 256 ? 1 : 0;
+  dim3 g1((unsigned)(a.N2 / C1::G), a.phase_split ? 2u : 1u, (unsigned)n_channels);
   if (a.N1 == 1024)
     QI_TRY((launch_p1<float, C1, 2, 1>(a, g1, st)));
   else if (a.N1 == 2048)

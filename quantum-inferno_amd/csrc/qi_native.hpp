@@ -39,6 +39,7 @@ struct RowArgs {
   T inv_len;
   float two_over_len;  // 2 / Lf (exact)
   int32_t neg_last_row;  // pass 1 of the linear kind: twiddle of t1 = N1 - 1 taken at t1 = -1
+  int32_t phase_split;   // pass 1 at N1 = 2048: one workgroup per decimation phase (set by the launcher)
   // pass 2 outputs
   cplx<T>* coef;
   T* bits;
