@@ -736,6 +736,7 @@ int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
       p->n % (native::kZoomD * native::kZoomSteps * 4) != 0)
     return -1;
   const int64_t M = Lf / native::kZoomD;
+  if (M % native::kBlk != 0 || !is_pow2(M / native::kBlk)) return -1;  // the coarse stage works in 4096-point planes
   if (4 * len <= M) return 0;
   if (2 * len <= M) return 1;
   if (4 * len <= 3 * M) return 2;
@@ -1117,6 +1118,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.X = X;
       z.Hc = static_cast<const cplx<T>*>(zt.Hc);
       z.coarse = zcoarse;
+      z.coarse_planes_log2 = 0;
+      while ((int64_t)native::kBlk << z.coarse_planes_log2 < zM) z.coarse_planes_log2++;
       z.stx = kind == 2 ? 1 : 0;
       // panel sample t is full-length sample t + off: linear correlation off = n/2 - 1, rolled circular n/2, Stockwell 0
       z.lane_off = kind == 0 ? 1 : 0;
@@ -1136,7 +1139,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
       QI_TRY(native::launch_zoom_gather<T>(z, ct, st));
-      QI_TRY(fft_c2c<T>(p->fft, zcoarse, zM, ct * zt.nzoom, HIPFFT_BACKWARD, st));
+      QI_TRY(native::launch_zoom_coarse<T>(z, ct, st));
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
       int order[3] = {0, 1, 2};
       std::stable_sort(order, order + 3, [&](int x, int y) { return znchunk[x] > znchunk[y]; });

@@ -378,6 +378,36 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   }
 }
 
+// Coarse stage of the zoom engine (qi_zoom.hip): workgroup (tau1, band, record) transforms the 4096 folded and
+// twiddled baseband bins that k_zoom_gather left in plane tau1 of the band, in place: afterwards
+// coarse[band][tau1][tau2] is the envelope sample tau = P tau2 + tau1 of the coarse grid.
+template <typename T>
+__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
+  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> tw256[256];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
+  cplx<T>* __restrict__ plane =
+      a.coarse + ((int64_t)blockIdx.z * a.nbands + blockIdx.y) * a.M + (int64_t)blockIdx.x * kBlk + col;
+  cplx<T> v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = plane[256 * b];
+  {
+    float s, c;
+    sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+    tw256[tid] = mk<T>((T)c, (T)s);
+  }
+  cplx<T> w;
+  {
+    float s, c;
+    sincospif((float)col * (2.0f / 4096.0f), &s, &c);
+    w = mk<T>((T)c, (T)s);
+  }
+  fft4096<T, 1>(v, buf, tw256, w, tid, col);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
+}
+
 // taps of a Gabor atom as a 4096-point circular-convolution kernel: g[(-u) mod 4096] = conj(psi(u + 1/2)), |u| <= W
 // (psi of styx_cwt.py:113-144 on the half-integer grid of an even-length record; out[t] = sum_u sig[t + u] conj(psi))
 __global__ void k_block_taps_gabor(double2* __restrict__ g, int w, const double* __restrict__ par, int nb_total,
@@ -469,6 +499,19 @@ int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels
   if (a.nitems <= 0) return QI_OK;
   dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
   return demod ? launch_block_v<float, true>(a, grid, st) : launch_block_v<float, false>(a, grid, st);
+}
+
+template <>
+int launch_zoom_coarse<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+  if (a.nbands <= 0) return QI_OK;
+  if (a.M < kBlk || a.M % kBlk != 0 || ((a.M / kBlk) & (a.M / kBlk - 1)) != 0) {
+    set_error("zoom engine: coarse grid of %lld points is not a power-of-two multiple of %d", (long long)a.M, kBlk);
+    return QI_ERR_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)(a.M / kBlk), (unsigned)a.nbands, (unsigned)n_channels);
+  k_zoom_coarse<float><<<grid, kBlkThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
 }
 
 int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,

@@ -145,7 +145,8 @@ struct ZoomArgs {
   int32_t time_accumulate;         // add to the per-time planes instead of writing them (later launches of a call)
   const cplx<T>* X;        // [C][Lf] spectra of the records
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
-  cplx<T>* coarse;         // [C][nbands][M]: baseband spectra, then (after the batched inverse FFT) coarse samples
+  cplx<T>* coarse;         // [C][nbands][P][4096], P = M / 4096: coarse sample tau = P tau2 + tau1 at [tau1][tau2]
+  int32_t coarse_planes_log2;  // log2 P
   const float* weights;    // [taps][kZoomD] interpolation weights of the lanes
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
@@ -163,7 +164,9 @@ struct ZoomArgs {
 };
 int64_t zoom_groups(int64_t n);  // workgroups along time (partial slots per band, stat slots per chunk)
 template <typename T>
-int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
+int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);  // folded baseband bins, then
+template <typename T>
+int launch_zoom_coarse(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);  // their 4096-point transforms, in place (qi_block.hip)
 template <typename T>
 int launch_zoom(const ZoomArgs<T>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st);
 void zoom_weights(int cls, int lane_off, float* w /*[zoom_taps(cls)][kZoomD]*/);

@@ -27,32 +27,50 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
 
-// Baseband spectra of the zoom bands: coarse[c][j][kappa mod M] = Y_j[k_c + kappa] for the band's support, 0 elsewhere
-// (Y as the one-pass loader of qi_native.hip forms it: spectrum x compact bank, or shifted spectrum x Gaussian).
+// Input of the coarse stage (k_zoom_coarse, qi_block.hip): with the coarse grid of M = P * 4096 samples and
+// tau = P tau2 + tau1, the envelope b[tau] = sum_kappa Yc[kappa] exp(2 pi i kappa tau / M) is, for each tau1 < P, one
+// 4096-point transform of  in[tau1][kappa0] = exp(2 pi i kappa0 tau1 / M) sum_r Yc[kappa0 + 4096 r] exp(2 pi i r tau1 / P).
+// Yc = the band's occupied bins moved to baseband (Y as the one-pass loader of qi_native.hip forms it: spectrum x
+// compact bank, or shifted spectrum x Gaussian).  One thread per (kappa0, tau1), every block r that can hold occupied
+// bins visited; written to coarse[c][j][tau1][kappa0], transformed in place by the coarse stage.
 template <typename T, bool STX>
 __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
-  const int64_t kappa = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (kappa >= a.M) return;
+  const int32_t M = (int32_t)a.M, P = M / kBlk;
+  const int32_t e = (int32_t)(blockIdx.x * 256 + threadIdx.x);  // = tau1 * 4096 + kappa0
+  if (e >= M) return;
+  const int32_t kappa0 = e & (kBlk - 1);
+  const uint32_t tau1 = (uint32_t)(e / kBlk);
   const int j = blockIdx.y;
   const int64_t ch = blockIdx.z;
   const BandDesc bd = a.bands[j];
   const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
-  const int32_t ks = (int32_t)(kappa < a.M / 2 ? kappa : kappa - a.M);
-  const int32_t k = kc + ks;
-  cplx<T> y = mk<T>(T(0), T(0));
-  if (k >= bd.k_lo && k < bd.k_lo + bd.k_len) {
-    const cplx<T>* __restrict__ X = a.X + ch * a.Lf;
+  const int32_t ks_lo = bd.k_lo - kc, ks_hi = ks_lo + bd.k_len;  // support in baseband bins
+  const uint32_t lmask = (uint32_t)a.Lf - 1u;
+  const cplx<T>* __restrict__ X = a.X + ch * a.Lf;
+  cplx<T> acc = mk<T>(T(0), T(0));
+  for (int32_t r = 0; r < P; ++r) {
+    const int32_t kappa = r * kBlk + kappa0;
+    const int32_t ks = kappa < M / 2 ? kappa : kappa - M;
+    if (ks < ks_lo || ks >= ks_hi) continue;
+    const int32_t k = kc + ks;
+    cplx<T> y;
     if (STX) {
-      const uint32_t mask = (uint32_t)a.Lf - 1u;
-      const cplx<T> x = X[(uint32_t)(k + (int32_t)bd.shift) & mask];
-      const T e = (T)bd.coef * (T)k;
-      const T w = exp2_t(-e * e) * a.inv_len;
-      y = mk<T>(x.x * w, x.y * w);
+      const cplx<T> x = X[(uint32_t)(k + (int32_t)bd.shift) & lmask];
+      const T g0 = (T)bd.coef * (T)k;
+      const T g = exp2_t(-g0 * g0) * a.inv_len;
+      y = mk<T>(x.x * g, x.y * g);
     } else {
-      y = cmul(X[(uint32_t)k & ((uint32_t)a.Lf - 1u)], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
+      y = cmul(X[(uint32_t)k & lmask], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
     }
+    float sr, cr;
+    sincospif(2.0f * (float)(((uint32_t)r * tau1) & (uint32_t)(P - 1)) / (float)P, &sr, &cr);
+    const cplx<T> t = cmul(y, mk<T>((T)cr, (T)sr));
+    acc.x += t.x;
+    acc.y += t.y;
   }
-  a.coarse[((int64_t)ch * a.nbands + j) * a.M + kappa] = y;
+  float s, c;
+  sincospif(2.0f * (float)(((uint32_t)kappa0 * tau1) & ((uint32_t)M - 1u)) / (float)M, &s, &c);
+  a.coarse[((int64_t)ch * a.nbands + j) * a.M + e] = cmul(acc, mk<T>((T)c, (T)s));
 }
 
 // Fine stage.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands are at
@@ -81,7 +99,9 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   // lane i holds coarse sample tau_a + A - HALF + i of the band: step s interpolates from lanes s .. s + TAPS - 1.
   // The samples (and the descriptor) of the next band are requested a band ahead: two registers hide the one
   // memory latency of the band loop.
-  const uint32_t widx = (tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask;
+  const uint32_t wtau = (tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask;
+  // coarse sample tau = P tau2 + tau1 sits at plane tau1, position tau2 (the layout the coarse stage writes)
+  const uint32_t widx = (wtau & ((1u << a.coarse_planes_log2) - 1u)) * (uint32_t)kBlk + (wtau >> a.coarse_planes_log2);
   const int jj0 = a.band_first + blockIdx.y, jj_end = a.band_first + a.band_count;
   cplx<T> smp_next = mk<T>(T(0), T(0));
   BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.band_first];
