@@ -234,10 +234,14 @@ struct qi_plan {
     std::vector<NativeGroup> groups;
     void* Hc = nullptr;
     void* Hfull = nullptr;
-    native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip), by interpolator class
-    int32_t nzoom = 0, zoom_count[3] = {0, 0, 0};
+    native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip), by level
+    int32_t* d_zoom_plane_band = nullptr;  // owner band of every coarse plane
+    int32_t nzoom = 0, zoom_count[native::kZoomLevels] = {0, 0, 0, 0, 0};
+    int64_t zoom_planes = 0;  // 4096-sample planes of coarse storage per record
+    int zoom_max_level = 0;
     void release() {
       if (d_zoom) (void)hipFree(d_zoom);
+      if (d_zoom_plane_band) (void)hipFree(d_zoom_plane_band);
       if (d_bands) (void)hipFree(d_bands);
       if (d_gen_list) (void)hipFree(d_gen_list);
       if (Hc) (void)hipFree(Hc);
@@ -265,9 +269,9 @@ struct qi_plan {
   } blk[3];
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
-  int native_zoom_small = 0;    // classes of at most this many bands get one band per workgroup
+  int native_zoom_max_level = 3;  // finest coarse grid the zoom engine may use (level 4 costs more in the coarse stage than two-pass saves)
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
-  float* d_zoom_w[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // weights [class][lane offset]
+  float* d_zoom_w[native::kZoomLevels][2] = {};  // interpolation weights [level][lane offset]
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
   // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
   int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
@@ -439,36 +443,56 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
     for (const auto& d : bands)
       fprintf(stderr, "[qi plan] table %d (Lf = %lld) band %d: %s, support [%d, +%d)\n", kind, (long long)Lf, d.out_band,
               d.mode == 0 ? "one-pass loader" : (d.mode == 1 ? "two-pass" : "zoom"), d.k_lo, d.k_len);
-  // bands marked for the zoom engine (mode 2 + class) leave the pass-2 list, ordered by class
+  // bands marked for the zoom engine (mode 2 + level) leave the pass-2 list, ordered by level
   {
-    std::vector<native::BandDesc> zoom, rest;
-    for (int c = 0; c < 3; ++c) {
-      t.zoom_count[c] = 0;
-      for (const auto& d : bands)
-        if (d.mode == 2 + c) {
-          zoom.push_back(d);
-          t.zoom_count[c]++;
+    std::vector<native::BandDesc> rest;
+    std::vector<std::vector<native::BandDesc>> by_level(native::kZoomLevels);
+    for (const auto& d : bands) {
+      if (d.mode >= 2) by_level[d.mode - 2].push_back(d);
+      else rest.push_back(d);
+    }
+    // a level with only a few bands is not worth a launch of its own: they join the next occupied level up (at
+    // most two up: each level doubles their coarse grid and adds window samples)
+    for (int g = 0; g + 1 < native::kZoomLevels; ++g) {
+      if (by_level[g].empty() || by_level[g].size() >= 6) continue;
+      for (int h = g + 1; h <= g + 2 && h < native::kZoomLevels; ++h)
+        if (!by_level[h].empty()) {
+          by_level[h].insert(by_level[h].begin(), by_level[g].begin(), by_level[g].end());
+          by_level[g].clear();
+          break;
         }
     }
-    for (const auto& d : bands)
-      if (d.mode < 2) rest.push_back(d);
-    // a handful of class-1 bands is cheaper as part of the class-2 launch (longer interpolator, one launch less)
-    if (t.zoom_count[1] > 0 && t.zoom_count[1] < 6 && t.zoom_count[2] > 0) {
-      t.zoom_count[2] += t.zoom_count[1];
-      t.zoom_count[1] = 0;
+    std::vector<native::BandDesc> zoom;
+    t.zoom_planes = 0;
+    t.zoom_max_level = 0;
+    for (int g = 0; g < native::kZoomLevels; ++g) {
+      t.zoom_count[g] = (int32_t)by_level[g].size();
+      for (auto d : by_level[g]) {
+        d.edge_slot = g;                    // level of the band's coarse grid
+        d.edge = (int32_t)t.zoom_planes;    // first plane of its coarse array
+        t.zoom_planes += ((Lf / native::kZoomD) << g) / native::kBlk;
+        t.zoom_max_level = g;
+        zoom.push_back(d);
+      }
     }
     if (!zoom.empty()) {
       QI_HIP(hipMalloc((void**)&t.d_zoom, zoom.size() * sizeof(native::BandDesc)));
       QI_HIP(hipMemcpy(t.d_zoom, zoom.data(), zoom.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
       t.nzoom = (int32_t)zoom.size();
-      for (int c = 0; c < 3; ++c)
+      std::vector<int32_t> owner((size_t)t.zoom_planes);
+      for (size_t j = 0; j < zoom.size(); ++j) {
+        const int64_t planes = ((Lf / native::kZoomD) << zoom[j].edge_slot) / native::kBlk;
+        for (int64_t q = 0; q < planes; ++q) owner[(size_t)(zoom[j].edge + q)] = (int32_t)j;
+      }
+      QI_HIP(hipMalloc((void**)&t.d_zoom_plane_band, owner.size() * sizeof(int32_t)));
+      QI_HIP(hipMemcpy(t.d_zoom_plane_band, owner.data(), owner.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      for (int g = 0; g < native::kZoomLevels; ++g)
         for (int e = 0; e < 2; ++e) {
-          if (p->d_zoom_w[c][e]) continue;
-          const int taps = native::zoom_taps(c);
-          std::vector<float> w((size_t)native::kZoomD * taps);
-          native::zoom_weights(c, e, w.data());
-          QI_HIP(hipMalloc((void**)&p->d_zoom_w[c][e], w.size() * sizeof(float)));
-          QI_HIP(hipMemcpy(p->d_zoom_w[c][e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+          if (p->d_zoom_w[g][e] || t.zoom_count[g] == 0) continue;
+          std::vector<float> w((size_t)64 * native::zoom_taps(g));
+          native::zoom_weights(g, e, w.data());
+          QI_HIP(hipMalloc((void**)&p->d_zoom_w[g][e], w.size() * sizeof(float)));
+          QI_HIP(hipMemcpy(p->d_zoom_w[g][e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     bands.swap(rest);
@@ -728,18 +752,16 @@ int build_block_stx(qi_plan* p, const std::vector<BlockPick>& picks, const std::
   return finish_block_table<T>(p, 2, 1, picks, taps, st);
 }
 
-// Zoom engine class of a band with `len` occupied bins out of Lf (-1: not eligible): the coarse grid has M = Lf / 64
-// samples; the band is oversampled M / len times and the interpolator is sized for >= 4 (13 taps), >= 2 (19) or
-// >= 4/3 (37).
+// Zoom engine level of a band with `len` occupied bins out of Lf (-1: not eligible): the coarsest grid
+// M_g = (Lf / 64) << g on which the band is oversampled at least 4 times.
 int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
-  if (!p->native_zoom || table == 3 || len <= 0 || Lf % native::kZoomD != 0 ||
-      p->n % (native::kZoomD * native::kZoomSteps * 4) != 0)
-    return -1;
-  const int64_t M = Lf / native::kZoomD;
-  if (M % native::kBlk != 0 || !is_pow2(M / native::kBlk)) return -1;  // the coarse stage works in 4096-point planes
-  if (4 * len <= M) return 0;
-  if (2 * len <= M) return 1;
-  if (4 * len <= 3 * M) return 2;
+  if (!p->native_zoom || table == 3 || len <= 0 || Lf % native::kZoomD != 0) return -1;
+  const int64_t M0 = Lf / native::kZoomD;
+  if (M0 % native::kBlk != 0 || !is_pow2(M0 / native::kBlk)) return -1;  // the coarse stage works in 4096-point planes
+  for (int g = 0; g < native::kZoomLevels; ++g) {
+    if (p->n % ((int64_t)native::kZoomD * native::zoom_steps(g) * 4) != 0) return -1;
+    if (native::kZoomOversample * len <= (M0 << g)) return g <= p->native_zoom_max_level ? g : -1;
+  }
   return -1;
 }
 
@@ -921,31 +943,30 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // zoom engine launch (narrow bands of the main table): its chunks come last
   const auto& zt = p->nat[kind];
   const bool zoom = zt.nzoom > 0;
-  const int64_t zwaves = zoom ? native::zoom_groups(n) : 0;  // workgroups (4 waves each) along time
-  const int64_t zM = zoom ? zt.Lf / native::kZoomD : 0;
-  int znchunk[3] = {0, 0, 0}, zplanes = 0;
-  int64_t zstat_base[3] = {0, 0, 0}, zoom_stats = 0;
+  constexpr int NL = native::kZoomLevels;
+  int znchunk[NL] = {}, zplanes = 0;
+  int64_t zstat_base[NL] = {}, zgroups[NL] = {}, zoom_stats = 0, zslots = 0;
   const int chunk_z0 = chunk_total;
   if (zoom) {
-    // the interpolator classes are separate launches that share their per-time planes: the launch with the most
-    // chunks runs first and writes them, the others add to them
-    for (int c = 0; c < 3; ++c) {
-      if (zt.zoom_count[c] <= 0) continue;
-      int nc = (int)ceil_div(p->native_zoom_waves, 4 * zwaves * C);
+    // the levels are separate launches that share their per-time planes: the launch with the most chunks runs first
+    // and writes them, the others add to them
+    for (int g = 0; g < NL; ++g) {
+      if (zt.zoom_count[g] <= 0) continue;
+      zgroups[g] = native::zoom_groups(n, g);
+      int nc = (int)ceil_div(p->native_zoom_waves, 4 * zgroups[g] * C);
       if (nc < 1) nc = 1;
-      // a class of a few bands: one band per workgroup, or its launch is a handful of long serial waves
-      if (zt.zoom_count[c] <= p->native_zoom_small && zwaves * C < 1024) nc = zt.zoom_count[c];
-      if (nc > zt.zoom_count[c]) nc = zt.zoom_count[c];
-      znchunk[c] = nc;
+      if (nc > zt.zoom_count[g]) nc = zt.zoom_count[g];
+      znchunk[g] = nc;
       if (nc > zplanes) zplanes = nc;
-      zstat_base[c] = zoom_stats;
-      zoom_stats += (int64_t)nc * zwaves;
+      zstat_base[g] = zoom_stats;
+      zoom_stats += (int64_t)nc * zgroups[g];
+      if (zgroups[g] > zslots) zslots = zgroups[g];
     }
     chunk_total += zplanes;
   }
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
   if (blk_slots > nbk) nbk = blk_slots;
-  if (zwaves > nbk) nbk = zwaves;
+  if (zslots > nbk) nbk = zslots;
   const int64_t p2_stats = (int64_t)chunk_p2 * nblk_max;
   const int64_t stat_slots = p2_stats + blk_stats + zoom_stats + (shorts ? p->nedge : 0);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
@@ -962,7 +983,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
-  const size_t e_zc = zoom ? (size_t)zt.nzoom * zM * sizeof(cplx<T>) : 0;
+  const size_t e_zc = zoom ? (size_t)zt.zoom_planes * native::kBlk * sizeof(cplx<T>) : 0;
   const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_zc;
   if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
@@ -1111,15 +1132,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       native::ZoomArgs<T> z{};
       z.n = n;
       z.Lf = zt.Lf;
-      z.M = zM;
+      z.planes = zt.zoom_planes;
       z.nbands = zt.nzoom;
       z.panel_bands = (int32_t)B;
       z.bands = zt.d_zoom;
+      z.plane_band = zt.d_zoom_plane_band;
       z.X = X;
       z.Hc = static_cast<const cplx<T>*>(zt.Hc);
       z.coarse = zcoarse;
-      z.coarse_planes_log2 = 0;
-      while ((int64_t)native::kBlk << z.coarse_planes_log2 < zM) z.coarse_planes_log2++;
       z.stx = kind == 2 ? 1 : 0;
       // panel sample t is full-length sample t + off: linear correlation off = n/2 - 1, rolled circular n/2, Stockwell 0
       z.lane_off = kind == 0 ? 1 : 0;
@@ -1138,26 +1158,26 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-      QI_TRY(native::launch_zoom_gather<T>(z, ct, st));
-      QI_TRY(native::launch_zoom_coarse<T>(z, ct, st));
+      QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
+      QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
-      int order[3] = {0, 1, 2};
-      std::stable_sort(order, order + 3, [&](int x, int y) { return znchunk[x] > znchunk[y]; });
-      int first = 0;
+      int order[NL];
+      for (int g = 0; g < NL; ++g) order[g] = g;
+      std::stable_sort(order, order + NL, [&](int x, int y) { return znchunk[x] > znchunk[y]; });
       bool planes_written = false;
-      for (int oi = 0; oi < 3; ++oi) {
-        const int c = order[oi];
-        if (znchunk[c] <= 0) continue;
-        first = 0;
-        for (int q = 0; q < c; ++q) first += zt.zoom_count[q];
+      for (int oi = 0; oi < NL; ++oi) {
+        const int g = order[oi];
+        if (znchunk[g] <= 0) continue;
+        int first = 0;
+        for (int q = 0; q < g; ++q) first += zt.zoom_count[q];
         native::ZoomArgs<T> zc = z;
         zc.band_first = first;
-        zc.band_count = zt.zoom_count[c];
-        zc.weights = p->d_zoom_w[c][z.lane_off];
-        zc.stat_base = p2_stats + blk_stats + zstat_base[c];
+        zc.band_count = zt.zoom_count[g];
+        zc.weights = p->d_zoom_w[g][z.lane_off];
+        zc.stat_base = p2_stats + blk_stats + zstat_base[g];
         zc.time_accumulate = planes_written ? 1 : 0;
         p->prof.begin(st, QI_STAGE_ZOOM);
-        QI_TRY(native::launch_zoom<T>(zc, c, znchunk[c], ct, st));
+        QI_TRY(native::launch_zoom<T>(zc, g, znchunk[g], ct, st));
         p->prof.end(QI_STAGE_ZOOM, st);
         planes_written = true;
       }
@@ -1313,7 +1333,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM_SMALL")) p->native_zoom_small = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);

@@ -380,15 +380,14 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
 
 // Coarse stage of the zoom engine (qi_zoom.hip): workgroup (tau1, band, record) transforms the 4096 folded and
 // twiddled baseband bins that k_zoom_gather left in plane tau1 of the band, in place: afterwards
-// coarse[band][tau1][tau2] is the envelope sample tau = P tau2 + tau1 of the coarse grid.
+// plane tau1 of the band holds the envelope samples tau = P tau2 + tau1 of its coarse grid at [tau2].
 template <typename T>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
   __shared__ cplx<T> buf[16 * kBlkPad];
   __shared__ cplx<T> tw256[256];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
-  cplx<T>* __restrict__ plane =
-      a.coarse + ((int64_t)blockIdx.z * a.nbands + blockIdx.y) * a.M + (int64_t)blockIdx.x * kBlk + col;
+  cplx<T>* __restrict__ plane = a.coarse + ((int64_t)blockIdx.z * a.planes + blockIdx.x) * kBlk + col;
   cplx<T> v[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) v[b] = plane[256 * b];
@@ -502,13 +501,10 @@ int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels
 }
 
 template <>
-int launch_zoom_coarse<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+int launch_zoom_coarse<float>(const ZoomArgs<float>& a, int max_level, int64_t n_channels, hipStream_t st) {
   if (a.nbands <= 0) return QI_OK;
-  if (a.M < kBlk || a.M % kBlk != 0 || ((a.M / kBlk) & (a.M / kBlk - 1)) != 0) {
-    set_error("zoom engine: coarse grid of %lld points is not a power-of-two multiple of %d", (long long)a.M, kBlk);
-    return QI_ERR_UNSUPPORTED;
-  }
-  dim3 grid((unsigned)(a.M / kBlk), (unsigned)a.nbands, (unsigned)n_channels);
+  (void)max_level;
+  dim3 grid((unsigned)a.planes, 1, (unsigned)n_channels);  // every plane of every band is one 4096-point transform
   k_zoom_coarse<float><<<grid, kBlkThreads, 0, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;

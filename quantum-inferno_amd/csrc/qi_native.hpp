@@ -131,23 +131,31 @@ int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
 int launch_block_rotate_rows(double2* rows, int count, hipStream_t st);
 
 // ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
-constexpr int kZoomD = 64;      // fine samples per coarse sample (one wave lane per fine position)
-constexpr int kZoomSteps = 16;  // coarse steps (of 64 outputs each) one wave produces per band
-// interpolator classes: a band oversampled >= 4x, >= 2x, >= 4/3x on the coarse grid gets a 12-, 18-, 36-tap
-// Kaiser-windowed sinc (beta = 14; one more tap covers the half-open phase range)
-constexpr int zoom_taps(int cls) { return cls == 0 ? 13 : (cls == 1 ? 19 : 37); }
+// A band with K occupied bins is assigned the coarsest grid "level" g on which it is oversampled >= 4 times:
+// D = 64 >> g fine samples per coarse sample, M_g = (Lf / 64) << g coarse samples, S = 1 << g coarse samples per
+// wave-step (a wave-step = 64 consecutive outputs = the 64 lanes).  The interpolator is always the 12-tap
+// Kaiser-windowed sinc (beta = 14) in coarse-sample units; a wave-step spans S coarse intervals, so its window has
+// 12 + S samples and every lane carries the 12 + S weights of its own position in it.
+constexpr int kZoomD = 64;  // fine samples per coarse sample at level 0 (= the lanes of a wave)
+constexpr int kZoomLevels = 5;
+constexpr int zoom_span(int level) { return 1 << level; }                         // S
+constexpr int zoom_taps(int level) { return 12 + zoom_span(level); }               // window samples per wave-step
+constexpr int zoom_steps(int level) { return level <= 1 ? 16 : (32 >> level); }    // wave-steps per wave and band
+constexpr int kZoomOversample = 4;
 template <typename T>
 struct ZoomArgs {
-  int64_t n, Lf, M;        // M = Lf / kZoomD coarse samples per band
+  int64_t n, Lf;
+  int64_t planes;          // 4096-sample planes of coarse storage per record (all bands)
   int32_t nbands, panel_bands;
-  const BandDesc* bands;   // [nbands] device: one-pass ("pruned") descriptors of the zoom bands, by class
-  int32_t band_first, band_count;  // the fine launch's range of `bands` (one interpolator class)
+  const BandDesc* bands;   // [nbands] device: one-pass descriptors of the zoom bands, ordered by level; for these
+                           // bands `edge` = first plane of the band's coarse array, `edge_slot` = its level
+  const int32_t* plane_band;       // [planes] device: band (index into `bands`) that owns each coarse plane
+  int32_t band_first, band_count;  // the fine launch's range of `bands` (one level)
   int32_t time_accumulate;         // add to the per-time planes instead of writing them (later launches of a call)
   const cplx<T>* X;        // [C][Lf] spectra of the records
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
-  cplx<T>* coarse;         // [C][nbands][P][4096], P = M / 4096: coarse sample tau = P tau2 + tau1 at [tau1][tau2]
-  int32_t coarse_planes_log2;  // log2 P
-  const float* weights;    // [taps][kZoomD] interpolation weights of the lanes
+  cplx<T>* coarse;         // [C][planes][4096]: per band [P][4096], P = M_g / 4096: sample tau = P tau2 + tau1 at [tau1][tau2]
+  const float* weights;    // [taps][64] interpolation weights of the lanes (one table per level and lane offset)
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
   int64_t tau_off;
@@ -162,14 +170,14 @@ struct ZoomArgs {
   int32_t chunk_base, chunk_total;
   T power_scale, eps;
 };
-int64_t zoom_groups(int64_t n);  // workgroups along time (partial slots per band, stat slots per chunk)
+int64_t zoom_groups(int64_t n, int level);  // workgroups along time (partial slots per band, stat slots per chunk)
 template <typename T>
-int launch_zoom_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);  // folded baseband bins, then
+int launch_zoom_gather(const ZoomArgs<T>& a, int max_level, int64_t n_channels, hipStream_t st);  // folded baseband bins, then
 template <typename T>
-int launch_zoom_coarse(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);  // their 4096-point transforms, in place (qi_block.hip)
+int launch_zoom_coarse(const ZoomArgs<T>& a, int max_level, int64_t n_channels, hipStream_t st);  // their 4096-point transforms, in place (qi_block.hip)
 template <typename T>
-int launch_zoom(const ZoomArgs<T>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st);
-void zoom_weights(int cls, int lane_off, float* w /*[zoom_taps(cls)][kZoomD]*/);
+int launch_zoom(const ZoomArgs<T>& a, int level, int nchunk, int64_t n_channels, hipStream_t st);
+void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,

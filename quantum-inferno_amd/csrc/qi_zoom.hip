@@ -1,16 +1,18 @@
-// Zoom engine: the narrow-spectrum bands of a panel (long atoms: a few hundred to a few thousand occupied bins out of
-// a million) are slowly varying envelopes on a carrier.  Their occupied bins, moved to baseband, are transformed on a
-// COARSE time grid of M = Lf / 64 samples (one small batched inverse FFT per band), and the panel is produced from
-// that by band-limited interpolation -- a 12-tap Kaiser-windowed sinc on the >= 4x oversampled coarse grid, error
-// below 6e-7 of a unit tone at the band edge (where the spectrum is < 2^-30 of its peak), < 1e-9 in the bulk -- times
-// the carrier phasor.  About 50 instructions per output instead of a share of a million-point transform, nothing
-// discarded (the zero-padded half of the linear correlation is simply not evaluated), no intermediate: the kernel
-// is bound by the panel write.
+// Zoom engine: the narrow-spectrum bands of a panel (long atoms: a few hundred to a few ten thousand occupied bins
+// out of a million) are slowly varying envelopes on a carrier.  Their occupied bins, moved to baseband, are
+// transformed on a COARSE time grid on which the band is oversampled at least 4 times (one small inverse FFT per
+// band: k_zoom_gather + k_zoom_coarse), and the panel is produced from that by band-limited interpolation -- a 12-tap
+// Kaiser-windowed sinc (beta = 14), error below 6e-7 of a unit tone at the band edge (where the spectrum is < 2^-30
+// of its peak), < 1e-9 in the bulk -- times the carrier phasor.  About 50-80 instructions per output instead of a
+// share of a million-point transform, nothing discarded (the zero-padded half of the linear correlation is simply not
+// evaluated), no intermediate: the kernel is bound by the panel write.
 //
-// One wave = 64 lanes = the 64 fine positions between two coarse samples: lane L produces sample 64 tau + L for
-// kSteps consecutive tau; the coarse samples a step needs are uniform over the wave (scalar registers, taken from a
-// vector register by v_readlane), the 13 interpolation weights are per-lane constants, every store is a 512-byte
-// run.  Waves only meet for the per-band power sum (one barrier per band).  No MFMA: there is no dense contraction here.
+// The coarse grid has D = 64 >> level fine samples per coarse sample (level 0: the narrowest bands, D = 64; each
+// level doubles the bandwidth that can be carried).  One wave-step = 64 consecutive outputs = the 64 lanes of a wave;
+// it spans S = 1 << level coarse intervals, so its window holds 12 + S coarse samples, which are uniform over the
+// wave (scalar registers, taken from a vector register by v_readlane as the window slides); each lane carries the
+// 12 + S weights of its own position in the window (registers; zero outside its 12 taps).  Every store is a 512-byte
+// run.  Waves only meet for the per-band power sum (one barrier per band).  No MFMA: there is no dense contraction.
 #include "qi_common.hpp"
 #include "qi_device.hpp"
 #include "qi_native.hpp"
@@ -27,31 +29,29 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
 
-// Input of the coarse stage (k_zoom_coarse, qi_block.hip): with the coarse grid of M = P * 4096 samples and
+// Input of the coarse stage (k_zoom_coarse, qi_block.hip): with the band's coarse grid of M = P * 4096 samples and
 // tau = P tau2 + tau1, the envelope b[tau] = sum_kappa Yc[kappa] exp(2 pi i kappa tau / M) is, for each tau1 < P, one
 // 4096-point transform of  in[tau1][kappa0] = exp(2 pi i kappa0 tau1 / M) sum_r Yc[kappa0 + 4096 r] exp(2 pi i r tau1 / P).
 // Yc = the band's occupied bins moved to baseband (Y as the one-pass loader of qi_native.hip forms it: spectrum x
 // compact bank, or shifted spectrum x Gaussian).  One thread per (kappa0, tau1), every block r that can hold occupied
-// bins visited; written to coarse[c][j][tau1][kappa0], transformed in place by the coarse stage.
+// bins visited; written to the band's planes [tau1][kappa0], transformed in place by the coarse stage.
 template <typename T, bool STX>
 __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
-  const int32_t M = (int32_t)a.M, P = M / kBlk;
-  const int32_t e = (int32_t)(blockIdx.x * 256 + threadIdx.x);  // = tau1 * 4096 + kappa0
-  if (e >= M) return;
-  const int32_t kappa0 = e & (kBlk - 1);
-  const uint32_t tau1 = (uint32_t)(e / kBlk);
-  const int j = blockIdx.y;
+  const BandDesc bd = a.bands[a.plane_band[blockIdx.y]];  // blockIdx.y = plane of the record's coarse storage
+  const int32_t M = (int32_t)((a.Lf / kZoomD) << bd.edge_slot), P = M / kBlk;
+  const int32_t kappa0 = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+  const uint32_t tau1 = blockIdx.y - (uint32_t)bd.edge;
+  const int32_t e = (int32_t)tau1 * kBlk + kappa0;
   const int64_t ch = blockIdx.z;
-  const BandDesc bd = a.bands[j];
   const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
   const int32_t ks_lo = bd.k_lo - kc, ks_hi = ks_lo + bd.k_len;  // support in baseband bins
   const uint32_t lmask = (uint32_t)a.Lf - 1u;
   const cplx<T>* __restrict__ X = a.X + ch * a.Lf;
   cplx<T> acc = mk<T>(T(0), T(0));
-  for (int32_t r = 0; r < P; ++r) {
-    const int32_t kappa = r * kBlk + kappa0;
-    const int32_t ks = kappa < M / 2 ? kappa : kappa - M;
-    if (ks < ks_lo || ks >= ks_hi) continue;
+  // the occupied baseband bins congruent to kappa0 modulo 4096: ks = ks0, ks0 + 4096, ... < ks_hi
+  const int32_t ks0 = ks_lo + ((kappa0 - ks_lo) & (kBlk - 1));
+  for (int32_t ks = ks0; ks < ks_hi; ks += kBlk) {
+    const uint32_t r = ((uint32_t)ks & ((uint32_t)M - 1u)) / kBlk;  // block of the M-point grid that holds bin ks
     const int32_t k = kc + ks;
     cplx<T> y;
     if (STX) {
@@ -63,65 +63,66 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
       y = cmul(X[(uint32_t)k & lmask], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
     }
     float sr, cr;
-    sincospif(2.0f * (float)(((uint32_t)r * tau1) & (uint32_t)(P - 1)) / (float)P, &sr, &cr);
+    sincospif(2.0f * (float)((r * tau1) & (uint32_t)(P - 1)) / (float)P, &sr, &cr);
     const cplx<T> t = cmul(y, mk<T>((T)cr, (T)sr));
     acc.x += t.x;
     acc.y += t.y;
   }
   float s, c;
   sincospif(2.0f * (float)(((uint32_t)kappa0 * tau1) & ((uint32_t)M - 1u)) / (float)M, &s, &c);
-  a.coarse[((int64_t)ch * a.nbands + j) * a.M + e] = cmul(acc, mk<T>((T)c, (T)s));
+  a.coarse[((int64_t)ch * a.planes + bd.edge) * kBlk + e] = cmul(acc, mk<T>((T)c, (T)s));
 }
 
-// Fine stage.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands are at
-// baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
-template <typename T, int STEPS, int TAPS, bool PHASOR, bool COEF, bool BITS>
+// Fine stage of one level.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands
+// are at baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
+template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
-  constexpr int NW = kZoomThreads / kWave, HALF = (TAPS - 1) / 2;
-  static_assert(STEPS + TAPS - 1 <= kWave, "the window of one wave must fit its lanes");
+  constexpr int NW = kZoomThreads / kWave, S = zoom_span(LEVEL), TAPS = zoom_taps(LEVEL), STEPS = zoom_steps(LEVEL);
+  constexpr int HALF = 6, WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
+  static_assert(WIN <= kWave, "the window of one wave must fit its lanes");
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t ch = blockIdx.z;
   const int64_t gw = (int64_t)blockIdx.x * NW + wv;  // wave index along time
-  const uint32_t tau_a = (uint32_t)gw * STEPS;       // first coarse step of this wave
-  const uint32_t mmask = (uint32_t)a.M - 1u, lmask = (uint32_t)a.Lf - 1u;
+  const uint32_t step_a = (uint32_t)gw * STEPS;      // first wave-step of this wave
+  const uint32_t mmask = (uint32_t)((a.Lf / kZoomD) << LEVEL) - 1u, lmask = (uint32_t)a.Lf - 1u;
+  const int plog2 = ilog2((int)((a.Lf / kZoomD) / kBlk)) + LEVEL;  // log2 of the planes per band
   float wgt[TAPS];
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[j * kZoomD + lane];  // [tap][lane]: coalesced
+  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[j * kWave + lane];  // [tap][lane]: coalesced
   T colp[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) colp[s] = T(0);
   T mx = T(0);
   double plogp = 0.0;
-  const uint32_t t_base = tau_a * kZoomD + (uint32_t)lane;  // output sample of step s: t_base + 64 s
+  const uint32_t t_base = step_a * kZoomD + (uint32_t)lane;  // output sample of wave-step s: t_base + 64 s
   __shared__ double s_red[2][NW];
   int par = 0;  // double-buffered so that one barrier per band is enough
 
-  // lane i holds coarse sample tau_a + A - HALF + i of the band: step s interpolates from lanes s .. s + TAPS - 1.
-  // The samples (and the descriptor) of the next band are requested a band ahead: two registers hide the one
-  // memory latency of the band loop.
-  const uint32_t wtau = (tau_a + (uint32_t)a.tau_off - (uint32_t)HALF + (uint32_t)lane) & mmask;
-  // coarse sample tau = P tau2 + tau1 sits at plane tau1, position tau2 (the layout the coarse stage writes)
-  const uint32_t widx = (wtau & ((1u << a.coarse_planes_log2) - 1u)) * (uint32_t)kBlk + (wtau >> a.coarse_planes_log2);
+  // lane i holds coarse sample S (step_a + A) - HALF + i of the band: wave-step s interpolates from lanes s S ..
+  // s S + TAPS - 1.  Coarse sample tau = P tau2 + tau1 sits at plane tau1, position tau2 (the coarse stage's layout).
+  // The samples (and the descriptor) of the next band are requested a band ahead.
+  const uint32_t wtau = ((uint32_t)S * (step_a + (uint32_t)a.tau_off) - (uint32_t)HALF + (uint32_t)lane) & mmask;
+  const uint32_t widx = (wtau & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau >> plog2);
   const int jj0 = a.band_first + blockIdx.y, jj_end = a.band_first + a.band_count;
   cplx<T> smp_next = mk<T>(T(0), T(0));
   BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.band_first];
-  if (jj0 < jj_end) smp_next = a.coarse[((int64_t)ch * a.nbands + jj0) * a.M + widx];
+  if (jj0 < jj_end) smp_next = a.coarse[((int64_t)ch * a.planes + bd_next.edge) * kBlk + widx];
   for (int jj = jj0; jj < jj_end; jj += gridDim.y) {
     const BandDesc bd = bd_next;
     const cplx<T> smp = smp_next;
     if (jj + (int)gridDim.y < jj_end) {
       bd_next = a.bands[jj + gridDim.y];
-      smp_next = a.coarse[((int64_t)ch * a.nbands + jj + gridDim.y) * a.M + widx];
+      smp_next = a.coarse[((int64_t)ch * a.planes + bd_next.edge) * kBlk + widx];
     }
     cplx<T> P = mk<T>(T(1), T(0)), Q = mk<T>(T(1), T(0));
     if (PHASOR) {
-      // carrier: exp(2 pi i kc f / Lf), f = 64 (tau + A) + lane - e: per-lane factor P, per-step factor Q (lane i
-      // holds the factor of step i); the phases are exact integers modulo Lf
+      // carrier: exp(2 pi i kc f / Lf), f = 64 (step + A) + lane - e: per-lane factor P, per-step factor Q (lane i
+      // holds the factor of wave-step i); the phases are exact integers modulo Lf
       const uint32_t kc = (uint32_t)(bd.k_lo + bd.k_len / 2);
       double c, s;
       unit_root((kc * (uint32_t)(lane - a.lane_off)) & lmask, a.two_over_len, &c, &s);
       P = mk<T>((T)c, (T)s);
-      unit_root((kc * kZoomD * (tau_a + (uint32_t)a.tau_off + (uint32_t)lane)) & lmask, a.two_over_len, &c, &s);
+      unit_root((kc * kZoomD * (step_a + (uint32_t)a.tau_off + (uint32_t)lane)) & lmask, a.two_over_len, &c, &s);
       Q = mk<T>((T)c, (T)s);
     }
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * a.n;
@@ -130,39 +131,36 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     uint32_t tb = t_base;
     asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
     T rowacc = T(0), pl = T(0);
-    // interpolation: real parts of all steps, then imaginary parts (the wave-uniform coarse samples sit in scalar
-    // registers, taken from `smp` by v_readlane as the window slides; one part at a time keeps them within budget)
+    // interpolation: real parts of all wave-steps, then imaginary parts (the wave-uniform coarse samples sit in
+    // scalar registers; one part at a time keeps them within budget)
     T zr[STEPS], zi[STEPS];
     {
-      float sx[STEPS + TAPS - 1];
+      float sx[WIN];
 #pragma unroll
-      for (int i = 0; i < TAPS - 1; ++i) sx[i] = lane_value(smp.x, i);
+      for (int i = 0; i < WIN; ++i) sx[i] = lane_value(smp.x, i);
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
-        sx[s + TAPS - 1] = lane_value(smp.x, s + TAPS - 1);
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sx[s + j], acc);
+        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sx[s * S + j], acc);
         zr[s] = acc;
       }
     }
     {
-      float sy[STEPS + TAPS - 1];
+      float sy[WIN];
 #pragma unroll
-      for (int i = 0; i < TAPS - 1; ++i) sy[i] = lane_value(smp.y, i);
+      for (int i = 0; i < WIN; ++i) sy[i] = lane_value(smp.y, i);
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
-        sy[s + TAPS - 1] = lane_value(smp.y, s + TAPS - 1);
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sy[s + j], acc);
+        for (int j = 0; j < TAPS; ++j) acc = fmaf(wgt[j], sy[s * S + j], acc);
         zi[s] = acc;
       }
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-      const T br = zr[s], bi = zi[s];
-      cplx<T> z = mk<T>(br, bi);
+      cplx<T> z = mk<T>(zr[s], zi[s]);
       if (PHASOR) {
         const cplx<T> q = mk<T>(lane_value(Q.x, s), lane_value(Q.y, s));
         z = cmul_rn(z, cmul_rn(P, q));
@@ -179,7 +177,7 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     }
     plogp += (double)pl;
     if (a.part_band) {
-      // one partial per workgroup and band: wave sums through LDS, written by thread 0 a band later
+      // one partial per workgroup and band: wave sums through LDS
       const double r = wave_sum((double)rowacc);
       if (lane == 0) s_red[par][wv] = r;
       __syncthreads();
@@ -228,29 +226,32 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   }
 }
 
-template <typename T, int TAPS, bool PHASOR>
+template <typename T, int LEVEL, bool PHASOR>
 int launch_zoom_v(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
   const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
-  if (coef && bits) k_zoom<T, kZoomSteps, TAPS, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (coef) k_zoom<T, kZoomSteps, TAPS, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (bits) k_zoom<T, kZoomSteps, TAPS, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else k_zoom<T, kZoomSteps, TAPS, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
+  if (coef && bits) k_zoom<T, LEVEL, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (coef) k_zoom<T, LEVEL, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (bits) k_zoom<T, LEVEL, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else k_zoom<T, LEVEL, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
-template <typename T, int TAPS>
+template <typename T, int LEVEL>
 int launch_zoom_t(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
-  return a.stx ? launch_zoom_v<T, TAPS, false>(a, grid, st) : launch_zoom_v<T, TAPS, true>(a, grid, st);
+  return a.stx ? launch_zoom_v<T, LEVEL, false>(a, grid, st) : launch_zoom_v<T, LEVEL, true>(a, grid, st);
 }
 
 }  // namespace
 
-int64_t zoom_groups(int64_t n) { return n / ((int64_t)kZoomD * kZoomSteps * (kZoomThreads / kWave)); }
+int64_t zoom_groups(int64_t n, int level) {
+  return n / ((int64_t)kZoomD * zoom_steps(level) * (kZoomThreads / kWave));
+}
 
 template <>
-int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+int launch_zoom_gather<float>(const ZoomArgs<float>& a, int max_level, int64_t n_channels, hipStream_t st) {
   if (a.nbands <= 0) return QI_OK;
-  dim3 grid((unsigned)ceil_div(a.M, 256), (unsigned)a.nbands, (unsigned)n_channels);
+  (void)max_level;
+  dim3 grid((unsigned)(kBlk / 256), (unsigned)a.planes, (unsigned)n_channels);
   if (a.stx) k_zoom_gather<float, true><<<grid, 256, 0, st>>>(a);
   else k_zoom_gather<float, false><<<grid, 256, 0, st>>>(a);
   QI_LAUNCH_CHECK();
@@ -258,27 +259,31 @@ int launch_zoom_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipS
 }
 
 template <>
-int launch_zoom<float>(const ZoomArgs<float>& a, int cls, int nchunk, int64_t n_channels, hipStream_t st) {
+int launch_zoom<float>(const ZoomArgs<float>& a, int level, int nchunk, int64_t n_channels, hipStream_t st) {
   if (a.band_count <= 0) return QI_OK;
-  const int64_t groups = zoom_groups(a.n);
-  if (groups * kZoomD * kZoomSteps * (kZoomThreads / kWave) != a.n) {
+  const int64_t groups = zoom_groups(a.n, level);
+  if (groups < 1 || groups * kZoomD * zoom_steps(level) * (kZoomThreads / kWave) != a.n) {
     set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
-              kZoomD * kZoomSteps * (kZoomThreads / kWave));
+              kZoomD * zoom_steps(level) * (kZoomThreads / kWave));
     return QI_ERR_UNSUPPORTED;
   }
   dim3 grid((unsigned)groups, (unsigned)nchunk, (unsigned)n_channels);
-  switch (cls) {
-    case 0: return launch_zoom_t<float, zoom_taps(0)>(a, grid, st);
-    case 1: return launch_zoom_t<float, zoom_taps(1)>(a, grid, st);
-    default: return launch_zoom_t<float, zoom_taps(2)>(a, grid, st);
+  switch (level) {
+    case 0: return launch_zoom_t<float, 0>(a, grid, st);
+    case 1: return launch_zoom_t<float, 1>(a, grid, st);
+    case 2: return launch_zoom_t<float, 2>(a, grid, st);
+    case 3: return launch_zoom_t<float, 3>(a, grid, st);
+    case 4: return launch_zoom_t<float, 4>(a, grid, st);
+    default: set_error("zoom engine: level %d out of range", level); return QI_ERR_ARG;
   }
 }
 
-// Interpolation weights of lane L for tap j: h((j - half) - (L - e) / 64), h = Kaiser-windowed sinc (beta = 14) of
-// 2 half taps: half = 6, 9, 18 for the classes 0, 1, 2 (errors 6e-7, 4e-7, 3e-7 of a unit tone at the band edge)
-void zoom_weights(int cls, int lane_off, float* w) {
-  const int taps = zoom_taps(cls);
-  const double beta = 14.0, half = (double)((taps - 1) / 2);
+// Interpolation weights of lane L for window sample j of a wave-step at `level`: the lane sits x = (L - e) / D coarse
+// samples after the window's reference sample (index 6), D = 64 >> level; weight = h((j - 6) - x), h = 12-tap
+// Kaiser-windowed sinc (beta = 14), zero outside |.| < 6.  Layout [tap][lane].
+void zoom_weights(int level, int lane_off, float* w) {
+  const int taps = zoom_taps(level);
+  const double beta = 14.0, half = 6.0, D = (double)(kZoomD >> level);
   auto bessel_i0 = [](double x) {
     double sum = 1.0, term = 1.0;
     for (int k = 1; k < 64; ++k) {
@@ -289,10 +294,10 @@ void zoom_weights(int cls, int lane_off, float* w) {
     return sum;
   };
   const double i0b = bessel_i0(beta);
-  for (int lane = 0; lane < kZoomD; ++lane) {
-    const double phi = (double)(lane - lane_off) / kZoomD;
+  for (int lane = 0; lane < kWave; ++lane) {
+    const double pos = (double)(lane - lane_off) / D;
     for (int j = 0; j < taps; ++j) {
-      const double x = (double)j - half - phi;
+      const double x = (double)j - half - pos;
       double v = 0.0;
       if (std::fabs(x) < half) {
         const double r = x / half;
@@ -300,7 +305,7 @@ void zoom_weights(int cls, int lane_off, float* w) {
         const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
         v = sinc * win;
       }
-      w[j * kZoomD + lane] = (float)v;
+      w[j * kWave + lane] = (float)v;
     }
   }
 }
