@@ -152,6 +152,13 @@ int qi_cwt(qi_plan* plan, int bank, const void* sig, int64_t n_channels, const q
 /* styx_stx.stx_complex_any_scale_pow2 (styx_stx.py:195-236).  sig: [C][n] real. */
 int qi_stx(qi_plan* plan, const void* sig, int64_t n_channels, const qi_tfr_out* out, qi_stream stream);
 
+/* Both of the above on the same records in one call (bank = QI_BANK_STYX): the results are those of qi_cwt followed by
+ * qi_stx to within float rounding -- the Stockwell bands may be formed from the even bins of the zero-padded spectrum
+ * the CWT has just made instead of a second forward transform (the tutorials run both on every record,
+ * s04_tone_tfr.py:84-112). */
+int qi_cwt_stx(qi_plan* plan, int bank, const void* sig, int64_t n_channels, const qi_tfr_out* out_cwt,
+               const qi_tfr_out* out_stx, qi_stream stream);
+
 /* styx_fft.stft_complex_pow2 / stft_from_sig (styx_fft.py:14-57,152-187): scipy.signal.stft with
  * boundary="zeros", padded=True, detrend="constant", one-sided.  window: [seg] real (device);
  * scale multiplies every coefficient (1/sum(window), times 2 sqrt(pi)/seg for stft_from_sig).

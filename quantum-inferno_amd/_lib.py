@@ -62,6 +62,7 @@ PROTOTYPES = {
     "qi_plan_profile_read": (_int, [_P, _D, _I64, _i32]),
     "qi_cwt": (_int, [_P, _int, _P, _i64, C.POINTER(TfrOut), _P]),
     "qi_stx": (_int, [_P, _P, _i64, C.POINTER(TfrOut), _P]),
+    "qi_cwt_stx": (_int, [_P, _int, _P, _i64, C.POINTER(TfrOut), C.POINTER(TfrOut), _P]),
     "qi_stft_segments": (_i64, [_i64, _i64, _i64]),
     "qi_stft_scratch_bytes": (_i64, [_int, _i64, _i64, _i64, _i64, _i64]),
     "qi_stft": (_int, [_int, _int, _P, _i64, _i64, _P, _i64, _i64, _i64, _dbl, _P, _P, _dbl, _P, _i64, _P]),

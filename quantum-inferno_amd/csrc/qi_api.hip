@@ -236,6 +236,8 @@ struct qi_plan {
     void* Hfull = nullptr;
     native::BandDesc* d_zoom = nullptr;  // bands produced by the zoom engine (qi_zoom.hip), by level
     int32_t* d_zoom_plane_band = nullptr;  // owner band of every coarse plane
+    std::vector<std::pair<int32_t, int32_t>> h_zoom;  // (panel row, level) of the zoom bands
+    std::vector<int32_t> h_rows;                      // panel rows of the pass-2 bands
     int32_t nzoom = 0, zoom_count[native::kZoomLevels] = {0, 0, 0, 0, 0};
     int64_t zoom_planes = 0;  // 4096-sample planes of coarse storage per record
     int zoom_max_level = 0;
@@ -260,6 +262,7 @@ struct qi_plan {
     native::BlockItem* d_items = nullptr;  // one per workgroup, most expensive first
     int32_t nitems = 0, nplanes = 0;
     int64_t max_blocks = 0;  // partial slots a band row needs
+    std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
     void release() {
       if (bank) (void)hipFree(bank);
       if (d_bands) (void)hipFree(d_bands);
@@ -268,6 +271,11 @@ struct qi_plan {
     }
   } blk[3];
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
+  // qi_cwt_stx: the CWT leaves the zero-padded spectra of the records at the start of the scratch
+  const void* shared_sig = nullptr;
+  int64_t shared_C = 0;
+  bool shared_valid = false;
+  int32_t* d_band_slots[3] = {nullptr, nullptr, nullptr};  // per table kind: partial slots each band's engine writes
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_max_level = 3;  // finest coarse grid the zoom engine may use (level 4 costs more in the coarse stage than two-pass saves)
   int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
@@ -463,6 +471,7 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
         }
     }
     std::vector<native::BandDesc> zoom;
+    t.h_zoom.clear();
     t.zoom_planes = 0;
     t.zoom_max_level = 0;
     for (int g = 0; g < native::kZoomLevels; ++g) {
@@ -473,6 +482,7 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
         t.zoom_planes += ((Lf / native::kZoomD) << g) / native::kBlk;
         t.zoom_max_level = g;
         zoom.push_back(d);
+        t.h_zoom.push_back({d.out_band, g});
       }
     }
     if (!zoom.empty()) {
@@ -497,6 +507,8 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
     }
     bands.swap(rest);
   }
+  t.h_rows.clear();
+  for (const auto& d : bands) t.h_rows.push_back(d.out_band);
   if (bands.empty()) {  // every band is produced by the block / zoom engines: an empty but valid table
     t.Lf = Lf;
     t.ready = true;
@@ -662,6 +674,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     const int32_t nchunk = (int32_t)ceil_div(count, p->native_blk_bands);
     const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
     if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
+    for (int32_t q = first; q < (int32_t)list.size(); ++q) bt.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
     for (int32_t c = 0; c < nchunk; ++c) {
       const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
       const int32_t hi = first + (int32_t)((int64_t)count * (c + 1) / nchunk);
@@ -899,7 +912,8 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
 // the fused epilogue for every band, the edge correction of the short-atom bands, and a fixed-order finalisation of
 // the reductions.
 template <typename T>
-int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
+int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st,
+               bool may_share = false) {
   struct Sub {
     const qi_plan::NativeTable* t;
     int kernel_kind;
@@ -972,9 +986,26 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   const bool want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
-  const bool clear_parts = subs.size() > 1 || blocks || zoom;
+  // Every engine writes a dense prefix of its bands' partial slots and all of its stat slots, so nothing has to be
+  // cleared when the finalisation knows each band's slot count; only the short-atom table (a second pass-2 geometry
+  // plus the edge slot at the end of the row) keeps the cleared layout.
+  const bool clear_parts = shorts;
+  if (!shorts && !p->d_band_slots[kind]) {
+    std::vector<int32_t> slots((size_t)B, 0);
+    for (int32_t r : p->nat[kind].h_rows) slots[r] = (int32_t)nblk_max;
+    for (const auto& z : p->nat[kind].h_zoom) slots[z.first] = (int32_t)native::zoom_groups(n, z.second);
+    if (blocks)
+      for (const auto& b : bt.h_bands) slots[b.first] = b.second;
+    QI_HIP(hipMalloc((void**)&p->d_band_slots[kind], slots.size() * sizeof(int32_t)));
+    QI_HIP(hipMemcpy(p->d_band_slots[kind], slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   // scratch regions, each [Ct][...] without per-channel padding
-  const size_t e_x = (size_t)Lf0 * sizeof(cplx<T>);
+  // qi_cwt_stx: the Stockwell call can take its spectra from the even bins of the zero-padded spectra the CWT call
+  // left at the start of the scratch -- when nothing of this table needs the n-point spectrum as an array (every band
+  // on the zoom / block engines) and both calls hold all records in one tile
+  bool share = may_share && kind == 2 && p->shared_valid && p->shared_sig == sig_v && p->shared_C == C &&
+               p->nat[kind].h_rows.empty() && !shorts;
+  const size_t e_x = (size_t)(share ? 2 * Lf0 : Lf0) * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
   const size_t e_imd = (size_t)imd_elems * sizeof(cplx<T>);
   const size_t e_pb = (size_t)B * nbk * 8;
@@ -992,6 +1023,17 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   }
   int64_t Ct = (int64_t)((p->ws_bytes - 4096) / per_chan);
   if (Ct > C) Ct = C;
+  if (share && Ct != C) {
+    set_error("internal: shared spectra need all records in one tile");  // cannot happen: the CWT scratch is larger
+    return QI_ERR_STATE;
+  }
+  if (kind == 0) {  // what this call will leave behind for a following qi_cwt_stx Stockwell call
+    p->shared_valid = Ct == C;
+    p->shared_sig = sig_v;
+    p->shared_C = C;
+  } else if (!share) {
+    p->shared_valid = false;  // the scratch is about to be overwritten
+  }
   char* w = p->ws;
   auto carve = [&](size_t bytes) {
     char* r = w;
@@ -1058,7 +1100,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_HIP(hipEventRecord(p->ev_join, p->side));
     }
     p->prof.begin(st, QI_STAGE_FORWARD);
-    if (p->native_fwd) {
+    if (share) {
+      // X already holds the zero-padded spectra of these records
+    } else if (p->native_fwd) {
       native::RowArgs<T> f{};
       f.Lf = Lf0;
       f.n = n;
@@ -1138,6 +1182,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.bands = zt.d_zoom;
       z.plane_band = zt.d_zoom_plane_band;
       z.X = X;
+      z.x_shift = share ? 1 : 0;
       z.Hc = static_cast<const cplx<T>*>(zt.Hc);
       z.coarse = zcoarse;
       z.stx = kind == 2 ? 1 : 0;
@@ -1210,7 +1255,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nbk, stat_slots,
-                             st));
+                             st, shorts ? nullptr : p->d_band_slots[kind]));
     p->prof.end(QI_STAGE_EPILOGUE, st);
   }
   return QI_OK;
@@ -1401,6 +1446,8 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  for (auto* b : p->d_band_slots)
+    if (b) (void)hipFree(b);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)
       if (w) (void)hipFree(w);
@@ -1439,6 +1486,10 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
   }
   p->nat[bank].release();
   if (bank == QI_BANK_STYX) p->blk[0].release();
+  if (p->d_band_slots[bank]) {
+    (void)hipFree(p->d_band_slots[bank]);
+    p->d_band_slots[bank] = nullptr;
+  }
   double* d_par = nullptr;
   QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
   std::vector<double> host((size_t)4 * B);
@@ -1519,6 +1570,10 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
   p->nb_stx = B;
   p->nat[2].release();
   p->blk[2].release();
+  if (p->d_band_slots[2]) {
+    (void)hipFree(p->d_band_slots[2]);
+    p->d_band_slots[2] = nullptr;
+  }
   if (native_wanted(p, 2)) {
     // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef
     std::vector<native::BandDesc> bands;
@@ -1626,6 +1681,21 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
   if (p->nat[2].ready) return run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
+}
+
+int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* out_cwt, const qi_tfr_out* out_stx,
+               qi_stream stream) {
+  QI_REQUIRE(p && sig && out_cwt && out_stx, "null argument");
+  QI_REQUIRE(bank == QI_BANK_STYX, "qi_cwt_stx runs the styx bank (bank %d given)", bank);
+  QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
+  DeviceGuard g(p->d.device);
+  p->prof.unchain();
+  if (p->nat[2].ready) {
+    const int rc = run_native<float>(p, 2, sig, C, out_stx, (hipStream_t)stream, /*may_share=*/p->nat[bank].ready);
+    p->shared_valid = false;
+    return rc;
+  }
+  return qi_stx(p, sig, C, out_stx, stream);
 }
 
 // ---- STFT ----------------------------------------------------------------------------------------

@@ -121,7 +121,7 @@ struct EpiArgs {
 template <typename T>
 int launch_epilogue(const EpiArgs<T>& a, hipStream_t st);
 int launch_finalize(const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t C,
-                    int64_t B, int64_t nblk, int64_t nstat, hipStream_t st);
+                    int64_t B, int64_t nblk, int64_t nstat, hipStream_t st, const int32_t* band_slots = nullptr);
 
 template <typename T>
 int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,

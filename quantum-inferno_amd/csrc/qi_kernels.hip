@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(kEpiThreads) k_epilogue(EpiArgs<T> a) {
 __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ part_band,
                                                   const double* __restrict__ part_stat,
                                                   double* __restrict__ power_band, double* __restrict__ stats,
-                                                  int64_t B, int64_t nblk, int64_t nstat) {
+                                                  int64_t B, int64_t nblk, int64_t nstat,
+                                                  const int32_t* __restrict__ band_slots) {
   __shared__ double s[3][256 / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t c = blockIdx.y, j = blockIdx.x;
@@ -179,7 +180,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ par
   if (j < B) {
     if (!part_band || !power_band) return;
     const double* p = part_band + (c * B + j) * nblk;
-    for (int64_t i = tid; i < nblk; i += 256) a1 += p[i];
+    const int64_t used = band_slots ? band_slots[j] : nblk;  // slots the band's engine wrote (the rest is never read)
+    for (int64_t i = tid; i < used; i += 256) a1 += p[i];
   } else {
     if (!part_stat || !stats) return;
     const double* p = part_stat + c * nstat * 3;
@@ -405,9 +407,9 @@ int launch_epilogue(const EpiArgs<T>& a, hipStream_t st) {
 }
 
 int launch_finalize(const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t C,
-                    int64_t B, int64_t nblk, int64_t nstat, hipStream_t st) {
+                    int64_t B, int64_t nblk, int64_t nstat, hipStream_t st, const int32_t* band_slots) {
   dim3 g((unsigned)(B + 1), (unsigned)C);
-  k_finalize<<<g, 256, 0, st>>>(part_band, part_stat, power_band, stats, B, nblk, nstat);
+  k_finalize<<<g, 256, 0, st>>>(part_band, part_stat, power_band, stats, B, nblk, nstat, band_slots);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

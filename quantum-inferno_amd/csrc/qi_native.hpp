@@ -152,7 +152,8 @@ struct ZoomArgs {
   const int32_t* plane_band;       // [planes] device: band (index into `bands`) that owns each coarse plane
   int32_t band_first, band_count;  // the fine launch's range of `bands` (one level)
   int32_t time_accumulate;         // add to the per-time planes instead of writing them (later launches of a call)
-  const cplx<T>* X;        // [C][Lf] spectra of the records
+  const cplx<T>* X;        // [C][Lf << x_shift] spectra of the records
+  int32_t x_shift;         // 1: X is the spectrum of the records zero-padded to twice Lf (bin k of Lf = bin 2k)
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
   cplx<T>* coarse;         // [C][planes][4096]: per band [P][4096], P = M_g / 4096: sample tau = P tau2 + tau1 at [tau1][tau2]
   const float* weights;    // [taps][64] interpolation weights of the lanes (one table per level and lane offset)

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
   const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
   const int32_t ks_lo = bd.k_lo - kc, ks_hi = ks_lo + bd.k_len;  // support in baseband bins
   const uint32_t lmask = (uint32_t)a.Lf - 1u;
-  const cplx<T>* __restrict__ X = a.X + ch * a.Lf;
+  const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);
   cplx<T> acc = mk<T>(T(0), T(0));
   // the occupied baseband bins congruent to kappa0 modulo 4096: ks = ks0, ks0 + 4096, ... < ks_hi
   const int32_t ks0 = ks_lo + ((kappa0 - ks_lo) & (kBlk - 1));
@@ -55,12 +55,12 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
     const int32_t k = kc + ks;
     cplx<T> y;
     if (STX) {
-      const cplx<T> x = X[(uint32_t)(k + (int32_t)bd.shift) & lmask];
+      const cplx<T> x = X[((uint32_t)(k + (int32_t)bd.shift) & lmask) << a.x_shift];
       const T g0 = (T)bd.coef * (T)k;
       const T g = exp2_t(-g0 * g0) * a.inv_len;
       y = mk<T>(x.x * g, x.y * g);
     } else {
-      y = cmul(X[(uint32_t)k & lmask], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
+      y = cmul(X[((uint32_t)k & lmask) << a.x_shift], a.Hc[bd.src_off + (k - bd.k_lo)]);  // k < 0: bins modulo Lf
     }
     float sr, cr;
     sincospif(2.0f * (float)((r * tau1) & (uint32_t)(P - 1)) / (float)P, &sr, &cr);

@@ -216,13 +216,16 @@ class TfrPlan:
         _lib.check(self._lib.qi_plan_profile_read(self._handle, ms, cnt, len(_lib.STAGES)))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.STAGES)}
 
-    def _run(self, which, sig, coef, bits, reductions, power_scale, eps, out=None, reduced_out=None):
+    def _signal(self, sig):
         if sig.dtype != self.rdtype or not sig.is_cuda or sig.device != self.device:
             sig = sig.to(device=self.device, dtype=self.rdtype)
         sig = sig.contiguous()
         if sig.dim() != 2 or sig.shape[1] != self.n:
             raise ValueError(f"signal must be [channels, {self.n}], got {tuple(sig.shape)}")
-        n_ch = sig.shape[0]
+        return sig
+
+    def _outputs(self, which, n_ch, coef, bits, reductions, power_scale, eps, out, reduced_out):
+        """The TfrResult of one transform (new buffers, or those of `out`) and its C-ABI descriptor."""
         f_hz = self.freq.get(which)
         if f_hz is None:
             raise _lib.QiError("band table not set on this plan")
@@ -255,7 +258,7 @@ class TfrPlan:
                 res.power_time = res.reduced[:o1].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
                 res.power_band = res.reduced[o1:o2].view(n_ch, n_b)
                 res.stats = res.reduced[o2:].view(n_ch, 4)
-        out = _lib.TfrOut(
+        desc = _lib.TfrOut(
             coef=_lib.ptr(res.coef),
             bits=_lib.ptr(res.bits),
             power_band=_lib.ptr(res.power_band),
@@ -264,13 +267,34 @@ class TfrPlan:
             power_scale=float(power_scale),
             eps=float(eps),
         )
-        with torch.cuda.device(dev):
+        return res, desc
+
+    def _run(self, which, sig, coef, bits, reductions, power_scale, eps, out=None, reduced_out=None):
+        sig = self._signal(sig)
+        n_ch = sig.shape[0]
+        res, desc = self._outputs(which, n_ch, coef, bits, reductions, power_scale, eps, out, reduced_out)
+        with torch.cuda.device(self.device):
             if which == _lib.QI_TABLE_STX:
-                rc = self._lib.qi_stx(self._handle, _lib.ptr(sig), n_ch, C.byref(out), self._stream())
+                rc = self._lib.qi_stx(self._handle, _lib.ptr(sig), n_ch, C.byref(desc), self._stream())
             else:
-                rc = self._lib.qi_cwt(self._handle, which, _lib.ptr(sig), n_ch, C.byref(out), self._stream())
+                rc = self._lib.qi_cwt(self._handle, which, _lib.ptr(sig), n_ch, C.byref(desc), self._stream())
         _lib.check(rc)
         return res
+
+    def cwt_stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
+        """The styx CWT and the Stockwell transform of the same records in one call (qi_cwt_stx): (cwt, stx) results,
+        equal to `cwt(...)` then `stx(...)` to within float rounding; `out` / `reduced_out` are pairs."""
+        sig = self._signal(sig)
+        n_ch = sig.shape[0]
+        out = out or (None, None)
+        reduced_out = reduced_out or (None, None)
+        res_c, desc_c = self._outputs(_lib.QI_BANK_STYX, n_ch, coef, bits, reductions, power_scale, eps, out[0], reduced_out[0])
+        res_s, desc_s = self._outputs(_lib.QI_TABLE_STX, n_ch, coef, bits, reductions, power_scale, eps, out[1], reduced_out[1])
+        with torch.cuda.device(self.device):
+            rc = self._lib.qi_cwt_stx(self._handle, _lib.QI_BANK_STYX, _lib.ptr(sig), n_ch, C.byref(desc_c),
+                                      C.byref(desc_s), self._stream())
+        _lib.check(rc)
+        return res_c, res_s
 
     def cwt(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
         return self._run(_lib.QI_BANK_STYX, sig, coef, bits, reductions, power_scale, eps, out, reduced_out)

@@ -433,3 +433,27 @@ def test_native_engines_other_band_tables(order, fs):
         del a, b
     nat.close()
     ref.close()
+
+
+def test_fused_cwt_stx_call_matches_separate_calls():
+    """qi_cwt_stx (both transforms of the same records in one call, the Stockwell bands formed from the even bins of
+    the CWT's zero-padded spectrum) against qi_cwt followed by qi_stx: the CWT is the same computation (bit-equal),
+    the Stockwell panel agrees to float rounding; a second fused call reproduces the first bit for bit."""
+    n, fs, order = 1 << 20, 1000.0, 3
+    x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 2, np.float32) for c in range(2)])).cuda()
+    plan = _plan_with_all(n, fs, order, np.float32, channels=2)
+    sep_c = plan.cwt(x, coef=True, reductions=True)
+    sep_s = plan.stx(x, coef=True, reductions=True)
+    fus_c, fus_s = plan.cwt_stx(x, coef=True, reductions=True)
+    assert torch.equal(fus_c.coef, sep_c.coef) and torch.equal(fus_c.reduced, sep_c.reduced)
+    scale = float(sep_s.coef.abs().max())
+    assert float((fus_s.coef - sep_s.coef).abs().max()) / scale <= 2e-6
+    assert torch.allclose(fus_s.power_band, sep_s.power_band, rtol=1e-5)
+    assert torch.allclose(fus_s.power_time, sep_s.power_time, rtol=1e-4, atol=1e-7 * float(sep_s.power_time.max()))
+    assert torch.allclose(fus_s.stats[:, :3], sep_s.stats[:, :3], rtol=1e-5)
+    again_c, again_s = plan.cwt_stx(x, coef=True, reductions=True)
+    assert torch.equal(again_s.coef, fus_s.coef) and torch.equal(again_s.reduced, fus_s.reduced)
+    # a plain Stockwell call after the fused one stands on its own forward transform again
+    sep2 = plan.stx(x, coef=True, reductions=True)
+    assert torch.equal(sep2.coef, sep_s.coef)
+    plan.close()
