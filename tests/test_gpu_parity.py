@@ -457,3 +457,27 @@ def test_fused_cwt_stx_call_matches_separate_calls():
     sep2 = plan.stx(x, coef=True, reductions=True)
     assert torch.equal(sep2.coef, sep_s.coef)
     plan.close()
+
+
+def test_native_stockwell_two_million_samples():
+    """The largest native size: Stockwell transform of 2^21 samples (zoom, block and two-pass bands on a 2^21-point
+    spectrum) against the hipFFT engine."""
+    from quantum_inferno_amd import _lib
+
+    n, fs, order = 1 << 21, 1000.0, 3
+    x = torch.from_numpy(orc.synth_chirp(n, fs, 0, 1, np.float32)[None, :]).cuda()
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    ws = engine.TfrPlan.workspace_for(n, nb, np.float32, 1)
+    nat = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_AUTO)
+    ref = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        plan.set_stx_bands(order, fs)
+    a = nat.stx(x, coef=True, reductions=True)
+    b = ref.stx(x, coef=True, reductions=True)
+    scale = float(b.coef.abs().max())
+    assert float((a.coef - b.coef).abs().amax(dim=2).max()) / scale <= 2e-5
+    assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
+    assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
+    assert nat.stage_bands("zoom")[2] + nat.stage_bands("block")[2] > 0  # the native engine did run
+    nat.close()
+    ref.close()
