@@ -200,6 +200,21 @@ int qi_shannon_panel(int dtype, int device, const void* power, const void* mult,
                      int64_t n_bands, int64_t n, double deg_free, void* info, void* shannon_bits, void* isnr,
                      void* esnr, qi_stream stream);
 
+/* ---- 1-D Shannon information of a record and of its spectrum (tfr_info.py:97-200) --------------------------------
+ * Shannon / get_info_and_entropy_32 (tfr_info.py:97-133) on marginals [C][n]: info = -log2(m + eps32),
+ * entropy = m * info, isnr = log2(n) - info, esnr = entropy / (log2(n) / n).  Any output may be NULL. */
+int qi_shannon_1d(int dtype, int device, const void* marginal, int64_t n_channels, int64_t n, void* info, void* entropy,
+                  void* isnr, void* esnr, qi_stream stream);
+/* scratch for the two calls below */
+int64_t qi_shannon_scratch_bytes(int dtype, int64_t n_channels, int64_t n);
+/* ShannonTDR (tfr_info.py:138-147): sig_norm = sig / sqrt(sum sig^2) (may be NULL), marginal = sig_norm^2.  [C][n]. */
+int qi_shannon_tdr(int dtype, int device, const void* sig, int64_t n_channels, int64_t n, void* sig_norm, void* marginal,
+                   void* scratch, int64_t scratch_bytes, qi_stream stream);
+/* ShannonFFT (tfr_info.py:163-183): spectrum = rfft(sig) [C][n/2+1] complex, angle = np.unwrap(np.angle(spectrum))
+ * (may be NULL), marginal = |spectrum|^2 / sum |spectrum|^2. */
+int qi_shannon_fft(int dtype, int device, const void* sig, int64_t n_channels, int64_t n, void* spectrum, void* angle,
+                   void* marginal, void* scratch, int64_t scratch_bytes, qi_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,28 @@ def panel_digest(panel, rows):
     }
 
 
+def gen_shannon1d():
+    """1-D Shannon family (tfr_info.py:97-200) on chirp + noise records (no empty spectrum bins, so that the unwrapped
+    phase is well defined), float64 and float32."""
+    d = {}
+    rng = np.random.default_rng(20250213)
+    for tag, dt, n in (("f64", np.float64, 4096), ("f32", np.float32, 4096), ("f64_odd", np.float64, 1000)):
+        sig = (synth_chirp(n, 1000.0, dtype=np.float64) + 0.5 * rng.standard_normal(n)).astype(dt)
+        tdr, fft = tfr_info.shannon_tdr_fft(sig)
+        d[f"sig_{tag}"] = sig
+        for name, obj in (("tdr", tdr), ("fft", fft)):
+            d[f"{name}_sig_{tag}"] = obj.sig
+            d[f"{name}_marginal_{tag}"] = obj.marginal
+            d[f"{name}_info_{tag}"] = obj.info
+            d[f"{name}_entropy_{tag}"] = obj.entropy
+            d[f"{name}_ref_entropy_{tag}"] = np.array(obj.ref_entropy)
+            d[f"{name}_isnr_{tag}"] = obj.isnr
+            d[f"{name}_esnr_{tag}"] = obj.esnr
+        d[f"fft_angle_{tag}"] = fft.angle_rads
+        d[f"fft_frequency_{tag}"] = fft.frequency
+    save("shannon1d.npz", **d)
+
+
 def gen_sized(log2n, orders, fs, name):
     d = {}
     n = 2 ** log2n
@@ -237,7 +259,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "medium"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "shannon1d", "medium"] + (["large"] if a.large else [])
     if "bands" in todo:
         gen_bands()
     if "small" in todo:
@@ -246,6 +268,8 @@ if __name__ == "__main__":
         gen_stft()
     if "stxgen" in todo:
         gen_stx_general()
+    if "shannon1d" in todo:
+        gen_shannon1d()
     if "medium" in todo:
         gen_sized(13, (3, 12), 1000.0, "medium_n8192.npz")
     if "large" in todo:

@@ -457,6 +457,25 @@ def shannon_1d(marginal):
     return info, ent, ref, np.log2(len(info)) - info, ent / ref
 
 
+def shannon_tdr(sig):
+    """(sig_norm, marginal) of ShannonTDR.  ref: tfr_info.py:138-147."""
+    sig = np.asarray(sig)
+    sig_norm = sig / np.sqrt(np.sum(sig ** 2))
+    return sig_norm, sig_norm ** 2
+
+
+def shannon_fft(sig):
+    """(spectrum, angle_rads, frequency, marginal) of ShannonFFT.  ref: tfr_info.py:163-183 (scipy.fft.rfft keeps
+    single precision for float32 input)."""
+    import scipy.fft as sfft
+
+    spec = sfft.rfft(x=np.asarray(sig))
+    angle = np.unwrap(np.angle(spec))
+    freq = np.arange(len(angle)) / len(angle) / 2.0
+    fft_sq = np.abs(spec) ** 2
+    return spec, angle, freq, fft_sq / np.sum(fft_sq)
+
+
 # --------------------------------------------------------------------------- synthetic input
 def synth_chirp(n, fs, channel=0, n_channels=1, dtype=np.float32, seed=20250213):
     """Seeded log-chirp test input defined in SURVEY.md s8(d) (this build's own

@@ -72,6 +72,10 @@ PROTOTYPES = {
     "qi_power_marginals_scratch_bytes": (_i64, [_i64, _i64, _i64]),
     "qi_log2_offset": (_int, [_int, _int, _P, _P, _i64, _i64, _dbl, _P, _P]),
     "qi_shannon_panel": (_int, [_int, _int, _P, _P, _int, _i64, _i64, _i64, _dbl, _P, _P, _P, _P, _P]),
+    "qi_shannon_1d": (_int, [_int, _int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    "qi_shannon_scratch_bytes": (_i64, [_int, _i64, _i64]),
+    "qi_shannon_tdr": (_int, [_int, _int, _P, _i64, _i64, _P, _P, _P, _i64, _P]),
+    "qi_shannon_fft": (_int, [_int, _int, _P, _i64, _i64, _P, _P, _P, _P, _i64, _P]),
 }
 
 _lib = None

@@ -1319,6 +1319,23 @@ int welch_impl(int device, const void* sig, int64_t C, int64_t n, const void* wi
 
 }  // namespace
 
+namespace {
+template <typename T>
+int shannon_fft_impl(int device, const T* sig, int64_t C, int64_t n, cplx<T>* spectrum, T* angle, T* marginal,
+                     char* scratch, hipStream_t st) {
+  const int64_t nf = n / 2 + 1;
+  double* partial = reinterpret_cast<double*>(scratch);
+  int32_t* turns = reinterpret_cast<int32_t*>(scratch + align_up((size_t)C * shannon_spans(n) * 8));
+  T* copy = reinterpret_cast<T*>(scratch + align_up((size_t)C * shannon_spans(n) * 8) + align_up((size_t)C * nf * 4));
+  QI_HIP(hipMemcpyAsync(copy, sig, (size_t)C * n * sizeof(T), hipMemcpyDeviceToDevice, st));
+  {
+    std::lock_guard<std::mutex> lock(g_stft_mu);
+    QI_TRY(fft_r2c<T>(g_stft_fft[device], copy, spectrum, n, C, st));
+  }
+  return launch_fft_marginal<T>(spectrum, C, nf, angle, marginal, partial, turns, st);
+}
+}  // namespace
+
 extern "C" {
 
 int qi_abi_version(void) { return QI_TFR_ABI_VERSION; }
@@ -1798,6 +1815,53 @@ int qi_shannon_panel(int dtype, int device, const void* power, const void* mult,
                                       (hipStream_t)stream)
              : launch_shannon<float>((const float*)power, (const float*)mult, mode, C, B, n, deg_free, (float*)info,
                                      (float*)shannon_bits, (float*)isnr, (float*)esnr, (hipStream_t)stream);
+}
+
+// ---- 1-D Shannon family ---------------------------------------------------------------------------------------------
+int qi_shannon_1d(int dtype, int device, const void* marginal, int64_t C, int64_t n, void* info, void* entropy,
+                  void* isnr, void* esnr, qi_stream stream) {
+  QI_REQUIRE(marginal, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && n > 1, "bad shape");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? launch_shannon_1d<double>((const double*)marginal, C, n, (double*)info, (double*)entropy,
+                                                     (double*)isnr, (double*)esnr, (hipStream_t)stream)
+                         : launch_shannon_1d<float>((const float*)marginal, C, n, (float*)info, (float*)entropy,
+                                                    (float*)isnr, (float*)esnr, (hipStream_t)stream);
+}
+
+int64_t qi_shannon_scratch_bytes(int dtype, int64_t C, int64_t n) {
+  if (C <= 0 || n <= 1) return 0;
+  const int64_t nf = n / 2 + 1, esz = dtype == QI_F64 ? 8 : 4;
+  // partial sums | unwrap turns | a copy of the records (the real-to-complex transform may overwrite its input)
+  return (int64_t)(align_up((size_t)C * shannon_spans(n) * 8) + align_up((size_t)C * nf * 4) + align_up((size_t)C * n * esz));
+}
+
+int qi_shannon_tdr(int dtype, int device, const void* sig, int64_t C, int64_t n, void* sig_norm, void* marginal,
+                   void* scratch, int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(sig && marginal && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && n > 1, "bad shape");
+  QI_REQUIRE(scratch_bytes >= qi_shannon_scratch_bytes(dtype, C, n), "scratch too small");
+  DeviceGuard g(device);
+  double* partial = static_cast<double*>(scratch);
+  return dtype == QI_F64 ? launch_tdr_marginal<double>((const double*)sig, C, n, (double*)sig_norm, (double*)marginal,
+                                                       partial, (hipStream_t)stream)
+                         : launch_tdr_marginal<float>((const float*)sig, C, n, (float*)sig_norm, (float*)marginal,
+                                                      partial, (hipStream_t)stream);
+}
+
+int qi_shannon_fft(int dtype, int device, const void* sig, int64_t C, int64_t n, void* spectrum, void* angle,
+                   void* marginal, void* scratch, int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(sig && spectrum && marginal && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && n > 1, "bad shape");
+  QI_REQUIRE(scratch_bytes >= qi_shannon_scratch_bytes(dtype, C, n), "scratch too small");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? shannon_fft_impl<double>(device, (const double*)sig, C, n, (double2*)spectrum, (double*)angle,
+                                                    (double*)marginal, (char*)scratch, (hipStream_t)stream)
+                         : shannon_fft_impl<float>(device, (const float*)sig, C, n, (float2*)spectrum, (float*)angle,
+                                                   (float*)marginal, (char*)scratch, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -120,6 +120,16 @@ struct EpiArgs {
 };
 template <typename T>
 int launch_epilogue(const EpiArgs<T>& a, hipStream_t st);
+// 1-D Shannon family (qi_shannon1d.hip)
+int64_t shannon_spans(int64_t n);
+template <typename T>
+int launch_shannon_1d(const T* m, int64_t C, int64_t n, T* info, T* entropy, T* isnr, T* esnr, hipStream_t st);
+template <typename T>
+int launch_tdr_marginal(const T* sig, int64_t C, int64_t n, T* sig_norm, T* marginal, double* partial, hipStream_t st);
+template <typename T>
+int launch_fft_marginal(const cplx<T>* X, int64_t C, int64_t nf, T* angle, T* marginal, double* partial, int32_t* turns,
+                        hipStream_t st);
+
 int launch_finalize(const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t C,
                     int64_t B, int64_t nblk, int64_t nstat, hipStream_t st, const int32_t* band_slots = nullptr);
 

@@ -159,3 +159,127 @@ class ShannonStftPerFreq(ShannonStft):
         p, _, _ = _as_panel(tfr_power)
         band, _, _ = power_marginals(p)
         super().__init__(tfr_power, p.shape[2], _mult=1.0 / band + _EPS, _mode=2)
+
+
+# ---- 1-D Shannon information of a record and of its spectrum (tfr_info.py:97-200) -----------------------------------
+def _as_rows(x):
+    """-> (tensor [C, n] on the GPU, was_numpy, was_1d)."""
+    was_numpy = not isinstance(x, torch.Tensor)
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(x))) if was_numpy else x
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.to(torch.float64)
+    if not t.is_cuda:
+        t = t.to(engine.default_device())
+    one = t.dim() == 1
+    if one:
+        t = t.unsqueeze(0)
+    if t.dim() != 2:
+        raise TypeError(f"Cannot handle an array of shape {tuple(t.shape)}.")
+    return t.contiguous(), was_numpy, one
+
+
+def _rows_back(t, was_numpy, one):
+    if one:
+        t = t[0]
+    return t.cpu().numpy() if was_numpy else t
+
+
+def _shannon_1d(marginal):
+    """(info, entropy, isnr, esnr) of marginals [C, n] (qi_shannon_1d)."""
+    lib = _lib.require_gpu()
+    n_ch, n = marginal.shape
+    outs = [torch.empty_like(marginal) for _ in range(4)]
+    with torch.cuda.device(marginal.device):
+        _lib.check(lib.qi_shannon_1d(_code(marginal), marginal.device.index, _lib.ptr(marginal), n_ch, n,
+                                     *[_lib.ptr(o) for o in outs], _lib.stream_ptr(marginal.device)))
+    return outs
+
+
+def get_info_and_entropy_32(marginal):
+    """info, entropy and reference entropy of a 1-D marginal with EPSILON32 (tfr_info.py:97-104)."""
+    m, was_numpy, one = _as_rows(marginal)
+    info, entropy, _, _ = _shannon_1d(m)
+    n = m.shape[1]
+    return _rows_back(info, was_numpy, one), _rows_back(entropy, was_numpy, one), np.log2(n) / n
+
+
+class Shannon:
+    """Shannon information of a 1-D marginal (tfr_info.py:107-133): marginal, info, entropy, ref_entropy, isnr, esnr.
+    A leading channel axis is accepted."""
+
+    def __init__(self, marginal, _rows=None):
+        m, was_numpy, one = _rows if _rows is not None else _as_rows(marginal)
+        info, entropy, isnr, esnr = _shannon_1d(m)
+        back = lambda t: _rows_back(t, was_numpy, one)  # noqa: E731
+        self.marginal = back(m)
+        self.info = back(info)
+        self.entropy = back(entropy)
+        self.ref_entropy = np.log2(m.shape[1]) / m.shape[1]
+        self.isnr = back(isnr)
+        self.esnr = back(esnr)
+
+
+def _scratch(lib, t):
+    nbytes = int(lib.qi_shannon_scratch_bytes(_code(t), t.shape[0], t.shape[1]))
+    return torch.empty(nbytes, dtype=torch.uint8, device=t.device), nbytes
+
+
+class ShannonTDR(Shannon):
+    """Shannon information of the normalised record (tfr_info.py:136-158): sig = x / sqrt(sum x^2), marginal = sig^2."""
+
+    def __init__(self, sig_in_real):
+        lib = _lib.require_gpu()
+        x, was_numpy, one = _as_rows(sig_in_real)
+        sig = torch.empty_like(x)
+        marginal = torch.empty_like(x)
+        scratch, nbytes = _scratch(lib, x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.qi_shannon_tdr(_code(x), x.device.index, _lib.ptr(x), x.shape[0], x.shape[1], _lib.ptr(sig),
+                                          _lib.ptr(marginal), _lib.ptr(scratch), nbytes, _lib.stream_ptr(x.device)))
+        self.sig = _rows_back(sig, was_numpy, one)
+        super().__init__(None, _rows=(marginal, was_numpy, one))
+
+    def print_total_ref_entropy(self):
+        print("Ref entropy, time:", self.ref_entropy)
+
+    def print_total_entropy(self):
+        print("Total Entropy, time:", self.entropy.sum())
+
+    def print_total_marginal(self):
+        print("Sum of time marginal:", self.marginal.sum())
+
+
+class ShannonFFT(Shannon):
+    """Shannon information of the spectrum (tfr_info.py:161-188): sig = rfft(x), angle_rads = unwrap(angle(sig)),
+    frequency = arange / len / 2, marginal = |sig|^2 / sum |sig|^2."""
+
+    def __init__(self, sig_in_real):
+        lib = _lib.require_gpu()
+        x, was_numpy, one = _as_rows(sig_in_real)
+        n_ch, n = x.shape
+        nf = n // 2 + 1
+        spec = torch.empty((n_ch, nf), dtype=engine._complex_of(x.dtype), device=x.device)
+        angle = torch.empty((n_ch, nf), dtype=x.dtype, device=x.device)
+        marginal = torch.empty((n_ch, nf), dtype=x.dtype, device=x.device)
+        scratch, nbytes = _scratch(lib, x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.qi_shannon_fft(_code(x), x.device.index, _lib.ptr(x), n_ch, n, _lib.ptr(spec), _lib.ptr(angle),
+                                          _lib.ptr(marginal), _lib.ptr(scratch), nbytes, _lib.stream_ptr(x.device)))
+        self.sig = _rows_back(spec, was_numpy, one)
+        self.angle_rads = _rows_back(angle, was_numpy, one)
+        self.frequency = np.arange(nf) / nf / 2.0
+        super().__init__(None, _rows=(marginal, was_numpy, one))
+
+    def print_total_ref_entropy(self):
+        print("Ref entropy, frequency:", self.ref_entropy)
+
+    def print_total_entropy(self):
+        print("Total Entropy, frequency:", self.entropy.sum())
+
+    def print_total_marginal(self):
+        print("Sum of frequency marginal:", self.marginal.sum())
+
+
+def shannon_tdr_fft(sig_in_real):
+    """ShannonTDR and ShannonFFT of the record (tfr_info.py:191-200)."""
+    return ShannonTDR(sig_in_real), ShannonFFT(sig_in_real)

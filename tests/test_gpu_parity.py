@@ -481,3 +481,36 @@ def test_native_stockwell_two_million_samples():
     assert nat.stage_bands("zoom")[2] + nat.stage_bands("block")[2] > 0  # the native engine did run
     nat.close()
     ref.close()
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32), ("f64_odd", np.float64)])
+def test_shannon_1d_family_vs_reference(golden, tag, dtype):
+    """1-D Shannon TDR / FFT (tfr_info.py:97-200) against the reference's outputs (tests/golden/shannon1d.npz)."""
+    g = golden("shannon1d.npz")
+    sig = g[f"sig_{tag}"]
+    assert sig.dtype == dtype
+    tdr, fft = tfr_info.shannon_tdr_fft(sig)
+    rel = 1e-12 if dtype == np.float64 else 2e-6
+    assert tdr.sig.dtype == dtype and fft.marginal.dtype == dtype
+    np.testing.assert_allclose(tdr.sig, g[f"tdr_sig_{tag}"], rtol=rel, atol=rel * np.abs(g[f"tdr_sig_{tag}"]).max())
+    np.testing.assert_allclose(fft.sig, g[f"fft_sig_{tag}"], rtol=0, atol=rel * 10 * np.abs(g[f"fft_sig_{tag}"]).max())
+    np.testing.assert_array_equal(fft.frequency, g[f"fft_frequency_{tag}"])
+    # unwrapped phase: every bin of the chirp + noise record is far above rounding, so the 2 pi decisions agree
+    np.testing.assert_allclose(fft.angle_rads, g[f"fft_angle_{tag}"], rtol=0, atol=1e-8 if dtype == np.float64 else 2e-2)
+    if dtype == np.float32:  # the reference's float32 cumulative sum drifts; modulo 2 pi the phases agree closely
+        d = np.angle(np.exp(1j * (fft.angle_rads.astype(np.float64) - g[f"fft_angle_{tag}"].astype(np.float64))))
+        assert np.abs(d).max() <= 2e-3
+    for name, obj in (("tdr", tdr), ("fft", fft)):
+        m = g[f"{name}_marginal_{tag}"]
+        np.testing.assert_allclose(obj.marginal, m, rtol=10 * rel, atol=rel * m.max())
+        # info = -log2(m + eps32): compared where the marginal is not below the epsilon floor's rounding
+        np.testing.assert_allclose(obj.info, g[f"{name}_info_{tag}"], rtol=0, atol=1e-9 if dtype == np.float64 else 2e-4)
+        np.testing.assert_allclose(obj.entropy, g[f"{name}_entropy_{tag}"], rtol=1e-9 if dtype == np.float64 else 1e-4,
+                                   atol=rel * g[f"{name}_entropy_{tag}"].max())
+        assert obj.ref_entropy == float(g[f"{name}_ref_entropy_{tag}"])
+        np.testing.assert_allclose(obj.isnr, g[f"{name}_isnr_{tag}"], rtol=0, atol=1e-9 if dtype == np.float64 else 2e-4)
+        np.testing.assert_allclose(obj.esnr, g[f"{name}_esnr_{tag}"], rtol=1e-9 if dtype == np.float64 else 1e-4,
+                                   atol=10 * rel * g[f"{name}_esnr_{tag}"].max())
+    # batched records through the same kernels
+    both = tfr_info.ShannonTDR(np.stack([sig, sig[::-1]]))
+    np.testing.assert_array_equal(both.marginal[0], tdr.marginal)

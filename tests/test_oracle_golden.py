@@ -174,3 +174,20 @@ def test_welch(golden, dtype):
     assert np.allclose(p, g[f"welch_p_{dtype}"], rtol=1e-12 if dtype == "float64" else 2e-6, atol=0)
     _, p2 = orc.welch_power_pow2(sig, 1000.0, 300, nfft=512, overlap=100, alpha=0.5)
     assert np.allclose(p2, g[f"welch2_p_{dtype}"], rtol=1e-12 if dtype == "float64" else 2e-6, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32", "f64_odd"])
+def test_shannon_1d_family(golden, tag):
+    """1-D Shannon TDR / FFT (tfr_info.py:97-200): the oracle against the reference's own outputs, bit for bit."""
+    g = golden("shannon1d.npz")
+    sig = g[f"sig_{tag}"]
+    sig_norm, m_t = orc.shannon_tdr(sig)
+    spec, angle, freq, m_f = orc.shannon_fft(sig)
+    assert np.array_equal(sig_norm, g[f"tdr_sig_{tag}"]) and np.array_equal(m_t, g[f"tdr_marginal_{tag}"])
+    assert np.array_equal(spec, g[f"fft_sig_{tag}"]) and np.array_equal(angle, g[f"fft_angle_{tag}"])
+    assert np.array_equal(freq, g[f"fft_frequency_{tag}"]) and np.array_equal(m_f, g[f"fft_marginal_{tag}"])
+    for name, m in (("tdr", m_t), ("fft", m_f)):
+        info, ent, ref, isnr, esnr = orc.shannon_1d(m)
+        assert np.array_equal(info, g[f"{name}_info_{tag}"]) and np.array_equal(ent, g[f"{name}_entropy_{tag}"])
+        assert ref == float(g[f"{name}_ref_entropy_{tag}"])
+        assert np.array_equal(isnr, g[f"{name}_isnr_{tag}"]) and np.array_equal(esnr, g[f"{name}_esnr_{tag}"])
