@@ -200,6 +200,25 @@ int qi_shannon_panel(int dtype, int device, const void* power, const void* mult,
                      int64_t n_bands, int64_t n, double deg_free, void* info, void* shannon_bits, void* isnr,
                      void* esnr, qi_stream stream);
 
+/* ---- sliding-window STFT in scipy.signal.ShortTimeFFT's convention (utilities/short_time_fft.py:20-175) ------------
+ * Slice q (0 <= q < n_slices) covers the padded record from sample first + q * hop (first <= 0: ShortTimeFFT's
+ * p_min * hop - seg // 2); pad_mode 0 zeros, 1 edge, 2 even, 3 odd reflection; detrend 1 removes each slice's mean
+ * (stft_detrend(detr="constant")); the windowed slice is rotated left by `roll` before the transform (ShortTimeFFT's
+ * phase_shift = 0 convention: roll = seg // 2).  window: [seg] real, already scaled (ShortTimeFFT.scale_to).  Z: [C][nfft/2+1]
+ * [n_slices] complex or NULL; real_out: same shape real or NULL, real_kind 1 = |Z| (stft_tukey), 2 = |Z|^2
+ * (spectrogram_tukey). */
+int64_t qi_sliding_scratch_bytes(int dtype, int64_t n_channels, int64_t nfft, int64_t n_slices);
+int qi_sliding_stft(int dtype, int device, const void* sig, int64_t n_channels, int64_t n, const void* window,
+                    int64_t seg, int64_t hop, int64_t nfft, int64_t first, int64_t n_slices, int pad_mode, int detrend,
+                    int64_t roll, void* Z, void* real_out, int real_kind, void* scratch, int64_t scratch_bytes,
+                    qi_stream stream);
+/* ShortTimeFFT.istft (istft_tukey, short_time_fft.py:112-137): out[c][k - k0] for k0 <= k < k1 = sum over the slices
+ * covering k of irfft(S[:, q]) (rotated back by `roll`) [k - (first + q hop)] * dual_window[k - (first + q hop)].
+ * S: [C][nfft/2+1][n_slices]. */
+int qi_sliding_istft(int dtype, int device, const void* S, int64_t n_channels, const void* dual_window, int64_t seg,
+                     int64_t hop, int64_t nfft, int64_t first, int64_t n_slices, int64_t roll, int64_t k0, int64_t k1,
+                     void* out, void* scratch, int64_t scratch_bytes, qi_stream stream);
+
 /* ---- 1-D Shannon information of a record and of its spectrum (tfr_info.py:97-200) --------------------------------
  * Shannon / get_info_and_entropy_32 (tfr_info.py:97-133) on marginals [C][n]: info = -log2(m + eps32),
  * entropy = m * info, isnr = log2(n) - info, esnr = entropy / (log2(n) / n).  Any output may be NULL. */

@@ -202,6 +202,30 @@ def panel_digest(panel, rows):
     }
 
 
+def gen_short_time_fft():
+    """utilities/short_time_fft.py: stft_tukey / spectrogram_tukey / istft_tukey and the complex STFT of the same
+    ShortTimeFFT object (the input of the inverse)."""
+    from quantum_inferno.utilities import short_time_fft as stf
+
+    d = {}
+    rng = np.random.default_rng(7)
+    sig = (synth_chirp(4096, 800.0, dtype=np.float64) + 0.1 * rng.standard_normal(4096))
+    d["sig"] = sig
+    cases = [("a", 800.0, 0.25, 256, 128, "magnitude", "zeros"), ("b", 800.0, 0.5, 200, 150, "psd", "even"),
+             ("c", 800.0, 1.0, 128, 96, "magnitude", "odd"), ("d", 800.0, 0.25, 256, 192, "magnitude", "edge")]
+    d["cases"] = np.array([f"{c[0]},{c[1]},{c[2]},{c[3]},{c[4]},{c[5]},{c[6]}" for c in cases])
+    for tag, fs, alpha, seg, ov, scaling, padding in cases:
+        f, t, mag = quiet(stf.stft_tukey, sig, fs, alpha, seg, ov, scaling, padding)
+        f2, t2, sxx = quiet(stf.spectrogram_tukey, sig, fs, alpha, seg, ov, scaling, padding)
+        obj = quiet(stf.get_stft_object_tukey, fs, alpha, seg, ov, scaling)
+        S = obj.stft(sig)
+        ts, x = quiet(stf.istft_tukey, S, fs, alpha, seg, ov, scaling)
+        d[f"f_{tag}"], d[f"t_{tag}"], d[f"mag_{tag}"], d[f"sxx_{tag}"] = f, t, mag, sxx
+        d[f"S_{tag}"], d[f"ts_{tag}"], d[f"x_{tag}"] = S, ts, x
+        d[f"geom_{tag}"] = np.array([obj.p_min, obj.p_max(len(sig)), obj.hop, obj.mfft, obj.m_num_mid])
+    save("short_time_fft.npz", **d)
+
+
 def gen_shannon1d():
     """1-D Shannon family (tfr_info.py:97-200) on chirp + noise records (no empty spectrum bins, so that the unwrapped
     phase is well defined), float64 and float32."""
@@ -259,7 +283,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "shannon1d", "medium"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "shannon1d", "stfft", "medium"] + (["large"] if a.large else [])
     if "bands" in todo:
         gen_bands()
     if "small" in todo:
@@ -270,6 +294,8 @@ if __name__ == "__main__":
         gen_stx_general()
     if "shannon1d" in todo:
         gen_shannon1d()
+    if "stfft" in todo:
+        gen_short_time_fft()
     if "medium" in todo:
         gen_sized(13, (3, 12), 1000.0, "medium_n8192.npz")
     if "large" in todo:

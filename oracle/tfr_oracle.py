@@ -476,6 +476,131 @@ def shannon_fft(sig):
     return spec, angle, freq, fft_sq / np.sum(fft_sq)
 
 
+# --------------------------------------------------------------------------- ShortTimeFFT-convention STFT
+def tukey_symmetric(m, alpha):
+    """scipy.signal.windows.tukey(m, alpha) (sym=True).  ref call site: utilities/short_time_fft.py:53."""
+    if alpha <= 0:
+        return np.ones(m)
+    n = np.arange(0, m)
+    if alpha >= 1.0:
+        fac = np.linspace(-np.pi, np.pi, m)
+        w = np.zeros(m)
+        for k, a in enumerate([0.5, 0.5]):
+            w += a * np.cos(k * fac)
+        return w
+    width = int(np.floor(alpha * (m - 1) / 2.0))
+    n1, n2, n3 = n[0 : width + 1], n[width + 1 : m - width - 1], n[m - width - 1 :]
+    w1 = 0.5 * (1 + np.cos(np.pi * (-1 + 2.0 * n1 / alpha / (m - 1))))
+    w2 = np.ones(n2.shape)
+    w3 = 0.5 * (1 + np.cos(np.pi * (-2.0 / alpha + 1 + 2.0 * n3 / alpha / (m - 1))))
+    return np.concatenate((w1, w2, w3))
+
+
+class SlidingStft:
+    """scipy.signal.ShortTimeFFT (SciPy 1.15.3 signal/_short_time_fft.py) restated for the one configuration the
+    reference uses (utilities/short_time_fft.py:20-61): real symmetric Tukey window scaled to 'magnitude' / 'psd',
+    fft_mode='onesided', phase_shift=0, mfft = next power of two of the segment."""
+
+    def __init__(self, fs, alpha, seg, overlap, scaling="magnitude"):
+        self.T, self.hop, self.m_num, self.m_mid = 1.0 / fs, seg - overlap, seg, seg // 2
+        self.mfft = 2 ** int(np.ceil(np.log2(seg)))
+        win = tukey_symmetric(seg, alpha)
+        if scaling == "magnitude":
+            win = win * (1 / abs(sum(win)))
+        elif scaling == "psd":
+            win = win * (1 / np.sqrt(sum(win ** 2) / self.T))
+        self.win = win
+        self.f = np.fft.rfftfreq(self.mfft, self.T)
+        self.delta_t = self.hop * self.T
+
+    @property
+    def p_min(self):
+        w2 = self.win ** 2
+        n0 = -self.m_mid
+        for q_, n_ in enumerate(range(n0, n0 - self.m_num - 1, -self.hop)):
+            n_next = n_ - self.hop
+            if n_next + self.m_num <= 0 or all(w2[n_next:] == 0):
+                return -q_
+
+    def p_max(self, n):
+        w2 = self.win ** 2
+        q1 = n // self.hop
+        k1 = q1 * self.hop - self.m_mid
+        for q_, k_ in enumerate(range(k1, n + self.m_num, self.hop), start=q1):
+            n_next = k_ + self.hop
+            if n_next >= n or all(w2[: n - n_next] == 0):
+                return q_ + 1
+
+    def stft(self, x, padding="zeros", detrend=False):
+        """S[f, p - p_min] for p_min <= p < p_max(n)  (ShortTimeFFT.stft / stft_detrend(detr='constant'))."""
+        import scipy.fft as sfft
+
+        kw = {"zeros": dict(mode="constant", constant_values=(0, 0)), "edge": dict(mode="edge"),
+              "even": dict(mode="reflect", reflect_type="even"), "odd": dict(mode="reflect", reflect_type="odd")}[padding]
+        n = len(x)
+        p0, p1 = self.p_min, self.p_max(n)
+        k0 = p0 * self.hop - self.m_mid
+        k1 = k0 + (p1 - p0) * self.hop + self.m_num
+        x1 = np.pad(x[max(k0, 0) : min(k1, n)], [(-min(k0, 0), max(k1 - n, 0))], **kw)
+        p_s = self.m_mid % self.m_num
+        out = np.zeros((len(self.f), p1 - p0), dtype=complex)
+        for q, k_ in enumerate(range(0, (p1 - p0) * self.hop, self.hop)):
+            seg = x1[k_ : k_ + self.m_num]
+            if detrend:
+                seg = seg - np.mean(seg)
+            v = seg * self.win.conj()
+            if len(v) < self.mfft:
+                v = np.hstack((v, np.zeros(self.mfft - len(v), dtype=v.dtype)))
+            out[:, q] = sfft.rfft(np.roll(v, -p_s), n=self.mfft)
+        return out
+
+    @property
+    def dual_win(self):
+        w2 = self.win ** 2
+        dd = w2.copy()
+        for k_ in range(self.hop, self.m_num, self.hop):
+            dd[k_:] += w2[:-k_]
+            dd[:-k_] += w2[k_:]
+        return self.win / dd
+
+    def istft(self, S, k1):
+        """x[0:k1] (ShortTimeFFT.istft(S, k0=0, k1=k1))."""
+        import scipy.fft as sfft
+
+        p_s = self.m_mid % self.m_num
+        x = np.zeros(k1 + self.m_num)
+        for q in range(S.shape[1]):
+            xs = np.roll(sfft.irfft(S[:, q], n=self.mfft), p_s)[: self.m_num] * self.dual_win
+            i0 = (q + self.p_min) * self.hop - self.m_mid
+            lo = max(i0, 0)
+            hi = min(i0 + self.m_num, len(x))
+            if hi > lo:
+                x[lo:hi] += xs[lo - i0 : hi - i0]
+        return x[:k1]
+
+
+def stft_tukey(x, fs, alpha, seg, overlap, scaling="magnitude", padding="zeros"):
+    """(f, t, |stft_detrend(x, 'constant')|).  ref: utilities/short_time_fft.py:64-109."""
+    o = SlidingStft(fs, alpha, seg, overlap, scaling)
+    mag = np.abs(o.stft(x, padding, detrend=True))
+    return o.f, np.arange(start=0, stop=o.delta_t * mag.shape[1], step=o.delta_t), mag
+
+
+def spectrogram_tukey(x, fs, alpha, seg, overlap, scaling="magnitude", padding="zeros"):
+    """(f, t, |stft(x)|^2).  ref: utilities/short_time_fft.py:140-175."""
+    o = SlidingStft(fs, alpha, seg, overlap, scaling)
+    s = o.stft(x, padding, detrend=False)
+    sxx = s.real ** 2 + s.imag ** 2
+    return o.f, np.arange(start=0, stop=o.delta_t * sxx.shape[1], step=o.delta_t), sxx
+
+
+def istft_tukey(S, fs, alpha, seg, overlap, scaling="magnitude"):
+    """(timestamps, x).  ref: utilities/short_time_fft.py:112-137."""
+    o = SlidingStft(fs, alpha, seg, overlap, scaling)
+    last = int((S.shape[1] - 1) * o.hop)
+    return np.arange(start=0, stop=last / fs, step=1 / fs), o.istft(S, last)
+
+
 # --------------------------------------------------------------------------- synthetic input
 def synth_chirp(n, fs, channel=0, n_channels=1, dtype=np.float32, seed=20250213):
     """Seeded log-chirp test input defined in SURVEY.md s8(d) (this build's own

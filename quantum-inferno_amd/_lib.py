@@ -72,6 +72,9 @@ PROTOTYPES = {
     "qi_power_marginals_scratch_bytes": (_i64, [_i64, _i64, _i64]),
     "qi_log2_offset": (_int, [_int, _int, _P, _P, _i64, _i64, _dbl, _P, _P]),
     "qi_shannon_panel": (_int, [_int, _int, _P, _P, _int, _i64, _i64, _i64, _dbl, _P, _P, _P, _P, _P]),
+    "qi_sliding_scratch_bytes": (_i64, [_int, _i64, _i64, _i64]),
+    "qi_sliding_stft": (_int, [_int, _int, _P, _i64, _i64, _P, _i64, _i64, _i64, _i64, _i64, _int, _int, _i64, _P, _P, _int, _P, _i64, _P]),
+    "qi_sliding_istft": (_int, [_int, _int, _P, _i64, _P, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _P, _P, _i64, _P]),
     "qi_shannon_1d": (_int, [_int, _int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     "qi_shannon_scratch_bytes": (_i64, [_int, _i64, _i64]),
     "qi_shannon_tdr": (_int, [_int, _int, _P, _i64, _i64, _P, _P, _P, _i64, _P]),

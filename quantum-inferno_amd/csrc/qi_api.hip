@@ -119,6 +119,25 @@ int fft_r2c<double>(FftCache& fc, double* in, double2* out, int64_t len, int64_t
   return QI_OK;
 }
 
+template <typename T>
+int fft_c2r(FftCache& fc, cplx<T>* in, T* out, int64_t len, int64_t batch, hipStream_t st);
+template <>
+int fft_c2r<float>(FftCache& fc, float2* in, float* out, int64_t len, int64_t batch, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_C2R, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecC2R(h, (hipfftComplex*)in, out));
+  return QI_OK;
+}
+template <>
+int fft_c2r<double>(FftCache& fc, double2* in, double* out, int64_t len, int64_t batch, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_Z2D, len, batch, &h));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecZ2D(h, (hipfftDoubleComplex*)in, out));
+  return QI_OK;
+}
+
 // ---- optional per-stage timing with HIP events on the caller's stream (bench.py's roofline leg) ----
 struct Profiler {
   static constexpr int kStages = QI_STAGE_COUNT;
@@ -1321,6 +1340,38 @@ int welch_impl(int device, const void* sig, int64_t C, int64_t n, const void* wi
 
 namespace {
 template <typename T>
+int sliding_stft_impl(int device, const T* sig, int64_t C, int64_t n, const T* window, int64_t seg, int64_t hop,
+                      int64_t nfft, int64_t first, int64_t nseg, int pad_mode, int detrend, int64_t roll, cplx<T>* Z, T* R,
+                      int kind, char* scratch, hipStream_t st) {
+  const int64_t nf = nfft / 2 + 1;
+  T* frames = reinterpret_cast<T*>(scratch);
+  cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
+  QI_TRY(launch_sliding_frames<T>(sig, window, frames, C, n, seg, hop, nfft, nseg, first, pad_mode, detrend, roll, st));
+  {
+    std::lock_guard<std::mutex> lk(g_stft_mu);
+    QI_TRY(fft_r2c<T>(g_stft_fft[device], frames, F, nfft, C * nseg, st));
+  }
+  return launch_sliding_transpose<T>(F, Z, R, kind, C, nseg, nf, st);
+}
+
+template <typename T>
+int sliding_istft_impl(int device, const cplx<T>* S, int64_t C, const T* dual, int64_t seg, int64_t hop, int64_t nfft,
+                       int64_t first, int64_t nseg, int64_t roll, int64_t k0, int64_t k1, T* out, char* scratch,
+                       hipStream_t st) {
+  const int64_t nf = nfft / 2 + 1;
+  T* slices = reinterpret_cast<T*>(scratch);
+  cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
+  QI_TRY(launch_sliding_untranspose<T>(S, F, C, nseg, nf, st));
+  {
+    std::lock_guard<std::mutex> lk(g_stft_mu);
+    QI_TRY(fft_c2r<T>(g_stft_fft[device], F, slices, nfft, C * nseg, st));
+  }
+  return launch_sliding_overlap_add<T>(slices, dual, out, C, k0, k1, seg, hop, nfft, nseg, first, roll, st);
+}
+}  // namespace
+
+namespace {
+template <typename T>
 int shannon_fft_impl(int device, const T* sig, int64_t C, int64_t n, cplx<T>* spectrum, T* angle, T* marginal,
                      char* scratch, hipStream_t st) {
   const int64_t nf = n / 2 + 1;
@@ -1862,6 +1913,48 @@ int qi_shannon_fft(int dtype, int device, const void* sig, int64_t C, int64_t n,
                                                     (double*)marginal, (char*)scratch, (hipStream_t)stream)
                          : shannon_fft_impl<float>(device, (const float*)sig, C, n, (float2*)spectrum, (float*)angle,
                                                    (float*)marginal, (char*)scratch, (hipStream_t)stream);
+}
+
+// ---- sliding-window STFT in scipy.signal.ShortTimeFFT's convention ---------------------------------------------------
+int64_t qi_sliding_scratch_bytes(int dtype, int64_t C, int64_t nfft, int64_t n_slices) {
+  if (C <= 0 || nfft <= 0 || n_slices <= 0) return 0;
+  const size_t esz = dtype == QI_F64 ? 8 : 4;
+  return (int64_t)(align_up((size_t)C * n_slices * nfft * esz) + align_up((size_t)C * n_slices * (nfft / 2 + 1) * 2 * esz));
+}
+
+int qi_sliding_stft(int dtype, int device, const void* sig, int64_t C, int64_t n, const void* window, int64_t seg,
+                    int64_t hop, int64_t nfft, int64_t first, int64_t n_slices, int pad_mode, int detrend, int64_t roll,
+                    void* Z, void* real_out, int real_kind, void* scratch, int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(sig && window && scratch && (Z || real_out), "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && n > 0 && seg > 0 && hop > 0 && nfft >= seg && n_slices > 0 && roll >= 0 && roll < nfft, "bad shape");
+  QI_REQUIRE(pad_mode >= 0 && pad_mode <= 3 && (real_kind == 1 || real_kind == 2 || !real_out), "bad mode");
+  QI_REQUIRE(pad_mode < 2 || (-first <= n - 1 && first + (n_slices - 1) * hop + seg - n <= n - 1),
+             "reflective padding reaches further than the record is long");
+  QI_REQUIRE(scratch_bytes >= qi_sliding_scratch_bytes(dtype, C, nfft, n_slices), "scratch too small");
+  DeviceGuard g(device);
+  return dtype == QI_F64
+             ? sliding_stft_impl<double>(device, (const double*)sig, C, n, (const double*)window, seg, hop, nfft, first,
+                                         n_slices, pad_mode, detrend, roll, (double2*)Z, (double*)real_out, real_kind,
+                                         (char*)scratch, (hipStream_t)stream)
+             : sliding_stft_impl<float>(device, (const float*)sig, C, n, (const float*)window, seg, hop, nfft, first,
+                                        n_slices, pad_mode, detrend, roll, (float2*)Z, (float*)real_out, real_kind,
+                                        (char*)scratch, (hipStream_t)stream);
+}
+
+int qi_sliding_istft(int dtype, int device, const void* S, int64_t C, const void* dual_window, int64_t seg, int64_t hop,
+                     int64_t nfft, int64_t first, int64_t n_slices, int64_t roll, int64_t k0, int64_t k1, void* out,
+                     void* scratch, int64_t scratch_bytes, qi_stream stream) {
+  QI_REQUIRE(S && dual_window && out && scratch, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(C > 0 && seg > 0 && hop > 0 && nfft >= seg && n_slices > 0 && k1 > k0 && roll >= 0 && roll < nfft, "bad shape");
+  QI_REQUIRE(scratch_bytes >= qi_sliding_scratch_bytes(dtype, C, nfft, n_slices), "scratch too small");
+  DeviceGuard g(device);
+  return dtype == QI_F64
+             ? sliding_istft_impl<double>(device, (const double2*)S, C, (const double*)dual_window, seg, hop, nfft, first,
+                                          n_slices, roll, k0, k1, (double*)out, (char*)scratch, (hipStream_t)stream)
+             : sliding_istft_impl<float>(device, (const float2*)S, C, (const float*)dual_window, seg, hop, nfft, first,
+                                         n_slices, roll, k0, k1, (float*)out, (char*)scratch, (hipStream_t)stream);
 }
 
 }  // extern "C"

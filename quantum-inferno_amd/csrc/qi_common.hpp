@@ -120,6 +120,20 @@ struct EpiArgs {
 };
 template <typename T>
 int launch_epilogue(const EpiArgs<T>& a, hipStream_t st);
+// sliding-window STFT in scipy.signal.ShortTimeFFT's convention (qi_stft_sliding.hip)
+template <typename T>
+int launch_sliding_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                          int64_t nfft, int64_t nseg, int64_t first, int pad_mode, int detrend, int64_t roll,
+                          hipStream_t st);
+template <typename T>
+int launch_sliding_transpose(const cplx<T>* F, cplx<T>* Z, T* R, int kind, int64_t C, int64_t nseg, int64_t nf,
+                             hipStream_t st);
+template <typename T>
+int launch_sliding_untranspose(const cplx<T>* S, cplx<T>* F, int64_t C, int64_t nseg, int64_t nf, hipStream_t st);
+template <typename T>
+int launch_sliding_overlap_add(const T* slices, const T* dual, T* out, int64_t C, int64_t k0, int64_t k1, int64_t seg,
+                               int64_t hop, int64_t nfft, int64_t nseg, int64_t first, int64_t roll, hipStream_t st);
+
 // 1-D Shannon family (qi_shannon1d.hip)
 int64_t shannon_spans(int64_t n);
 template <typename T>

@@ -140,7 +140,8 @@ constexpr int kZoomD = 64;  // fine samples per coarse sample at level 0 (= the 
 constexpr int kZoomLevels = 5;
 constexpr int zoom_span(int level) { return 1 << level; }                         // S
 constexpr int zoom_taps(int level) { return 12 + zoom_span(level); }               // window samples per wave-step
-constexpr int zoom_steps(int level) { return level <= 1 ? 16 : (32 >> level); }    // wave-steps per wave and band
+constexpr int zoom_steps(int level) { return level <= 2 ? 16 : (64 >> level); }    // wave-steps per wave and band
+                                                                                   // (window of <= 128 coarse samples)
 constexpr int kZoomOversample = 4;
 template <typename T>
 struct ZoomArgs {

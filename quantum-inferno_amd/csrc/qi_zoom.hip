@@ -79,7 +79,8 @@ template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   constexpr int NW = kZoomThreads / kWave, S = zoom_span(LEVEL), TAPS = zoom_taps(LEVEL), STEPS = zoom_steps(LEVEL);
   constexpr int HALF = 6, WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
-  static_assert(WIN <= kWave, "the window of one wave must fit its lanes");
+  static_assert(WIN <= 2 * kWave, "the window of one wave must fit two registers of its lanes");
+  constexpr bool TWO = WIN > kWave;  // the window spills into a second vector register
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t ch = blockIdx.z;
   const int64_t gw = (int64_t)blockIdx.x * NW + wv;  // wave index along time
@@ -103,16 +104,24 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   // The samples (and the descriptor) of the next band are requested a band ahead.
   const uint32_t wtau = ((uint32_t)S * (step_a + (uint32_t)a.tau_off) - (uint32_t)HALF + (uint32_t)lane) & mmask;
   const uint32_t widx = (wtau & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau >> plog2);
+  const uint32_t wtau2 = (wtau + (uint32_t)kWave) & mmask;  // window samples 64 .. 127 (wide windows only)
+  const uint32_t widx2 = (wtau2 & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau2 >> plog2);
   const int jj0 = a.band_first + blockIdx.y, jj_end = a.band_first + a.band_count;
-  cplx<T> smp_next = mk<T>(T(0), T(0));
+  cplx<T> smp_next = mk<T>(T(0), T(0)), smq_next = mk<T>(T(0), T(0));
   BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.band_first];
-  if (jj0 < jj_end) smp_next = a.coarse[((int64_t)ch * a.planes + bd_next.edge) * kBlk + widx];
+  if (jj0 < jj_end) {
+    const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
+    smp_next = b[widx];
+    if (TWO) smq_next = b[widx2];
+  }
   for (int jj = jj0; jj < jj_end; jj += gridDim.y) {
     const BandDesc bd = bd_next;
-    const cplx<T> smp = smp_next;
+    const cplx<T> smp = smp_next, smq = smq_next;
     if (jj + (int)gridDim.y < jj_end) {
       bd_next = a.bands[jj + gridDim.y];
-      smp_next = a.coarse[((int64_t)ch * a.planes + bd_next.edge) * kBlk + widx];
+      const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
+      smp_next = b[widx];
+      if (TWO) smq_next = b[widx2];
     }
     cplx<T> P = mk<T>(T(1), T(0)), Q = mk<T>(T(1), T(0));
     if (PHASOR) {
@@ -137,7 +146,7 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     {
       float sx[WIN];
 #pragma unroll
-      for (int i = 0; i < WIN; ++i) sx[i] = lane_value(smp.x, i);
+      for (int i = 0; i < WIN; ++i) sx[i] = i < kWave ? lane_value(smp.x, i) : lane_value(smq.x, i - kWave);
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         T acc = T(0);
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
     {
       float sy[WIN];
 #pragma unroll
-      for (int i = 0; i < WIN; ++i) sy[i] = lane_value(smp.y, i);
+      for (int i = 0; i < WIN; ++i) sy[i] = i < kWave ? lane_value(smp.y, i) : lane_value(smq.y, i - kWave);
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         T acc = T(0);

@@ -514,3 +514,30 @@ def test_shannon_1d_family_vs_reference(golden, tag, dtype):
     # batched records through the same kernels
     both = tfr_info.ShannonTDR(np.stack([sig, sig[::-1]]))
     np.testing.assert_array_equal(both.marginal[0], tdr.marginal)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_short_time_fft_wrappers_vs_reference(golden, dtype):
+    """utilities/short_time_fft.py: stft_tukey, spectrogram_tukey (every padding mode, both scalings) and istft_tukey
+    against the reference's outputs (tests/golden/short_time_fft.npz)."""
+    from quantum_inferno_amd.utilities import short_time_fft as stf
+
+    g = golden("short_time_fft.npz")
+    sig = g["sig"].astype(dtype)
+    tol = 1e-11 if dtype == np.float64 else 2e-5
+    for line in g["cases"]:
+        tag, fs, alpha, seg, ov, scaling, padding = str(line).split(",")
+        fs, alpha, seg, ov = float(fs), float(alpha), int(seg), int(ov)
+        obj = stf.get_stft_object_tukey(fs, alpha, seg, ov, scaling)
+        assert [obj.p_min, obj.p_max(len(sig)), obj.hop, obj.mfft, obj.m_num_mid] == list(g[f"geom_{tag}"])
+        f, t, mag = stf.stft_tukey(sig, fs, alpha, seg, ov, scaling, padding)
+        assert np.array_equal(f, g[f"f_{tag}"]) and np.array_equal(t, g[f"t_{tag}"])
+        assert mag.dtype == dtype and relmax(mag, g[f"mag_{tag}"]) <= tol, (tag, relmax(mag, g[f"mag_{tag}"]))
+        _, _, sxx = stf.spectrogram_tukey(sig, fs, alpha, seg, ov, scaling, padding)
+        assert relmax(sxx, g[f"sxx_{tag}"]) <= 2 * tol, tag
+        cdt = np.complex128 if dtype == np.float64 else np.complex64
+        ts, x = stf.istft_tukey(g[f"S_{tag}"].astype(cdt), fs, alpha, seg, ov, scaling)
+        assert np.array_equal(ts, g[f"ts_{tag}"]) and relmax(x, g[f"x_{tag}"]) <= 10 * tol, (tag, relmax(x, g[f"x_{tag}"]))
+    # a batch of records through the same kernels
+    two = stf.stft_tukey(np.stack([sig, sig[::-1]]), 800.0, 0.25, 256, 128)[2]
+    assert np.array_equal(two[0], stf.stft_tukey(sig, 800.0, 0.25, 256, 128)[2])

@@ -191,3 +191,27 @@ def test_shannon_1d_family(golden, tag):
         assert np.array_equal(info, g[f"{name}_info_{tag}"]) and np.array_equal(ent, g[f"{name}_entropy_{tag}"])
         assert ref == float(g[f"{name}_ref_entropy_{tag}"])
         assert np.array_equal(isnr, g[f"{name}_isnr_{tag}"]) and np.array_equal(esnr, g[f"{name}_esnr_{tag}"])
+
+
+def _stfft_cases(g):
+    for line in g["cases"]:
+        tag, fs, alpha, seg, ov, scaling, padding = str(line).split(",")
+        yield tag, float(fs), float(alpha), int(seg), int(ov), scaling, padding
+
+
+def test_short_time_fft_wrappers(golden):
+    """utilities/short_time_fft.py (stft_tukey / spectrogram_tukey / istft_tukey over scipy.signal.ShortTimeFFT): the
+    oracle's restatement against the reference's outputs."""
+    g = golden("short_time_fft.npz")
+    sig = g["sig"]
+    for tag, fs, alpha, seg, ov, scaling, padding in _stfft_cases(g):
+        o = orc.SlidingStft(fs, alpha, seg, ov, scaling)
+        assert [o.p_min, o.p_max(len(sig)), o.hop, o.mfft, o.m_mid] == list(g[f"geom_{tag}"])
+        f, t, mag = orc.stft_tukey(sig, fs, alpha, seg, ov, scaling, padding)
+        assert np.array_equal(f, g[f"f_{tag}"]) and np.array_equal(t, g[f"t_{tag}"])
+        assert relmax(mag, g[f"mag_{tag}"]) <= 1e-13
+        _, _, sxx = orc.spectrogram_tukey(sig, fs, alpha, seg, ov, scaling, padding)
+        assert relmax(sxx, g[f"sxx_{tag}"]) <= 1e-13
+        assert relmax(o.stft(sig), g[f"S_{tag}"]) <= 1e-13
+        ts, x = orc.istft_tukey(g[f"S_{tag}"], fs, alpha, seg, ov, scaling)
+        assert np.array_equal(ts, g[f"ts_{tag}"]) and relmax(x, g[f"x_{tag}"]) <= 1e-12
