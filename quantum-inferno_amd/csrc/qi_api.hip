@@ -458,7 +458,10 @@ bool native_len_ok(int64_t Lf) { return Lf == (1ll << 20) || Lf == (1ll << 21); 
 bool native_wanted(const qi_plan* p, int kind) {
   if (p->d.engine == QI_ENGINE_HIPFFT || p->d.dtype != QI_F32) return false;
   const int64_t Lf = kind == 0 ? p->L : p->n;
-  return is_pow2(p->n) && native_len_ok(Lf);
+  if (is_pow2(p->n) && native_len_ok(Lf)) return true;
+  // Stockwell tables usually have no band for the two-pass kernels (exact Gaussian windows: every band is a zoom or a
+  // block band), and those two engines take any power-of-two length from 2^18: the table build decides
+  return kind == 2 && is_pow2(p->n) && p->n >= (1 << 18) && p->n <= (1ll << 26);
 }
 
 // Order the bands into launch groups: the wide bands are dealt out `native_group` per group (all in one group when
@@ -1121,7 +1124,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     p->prof.begin(st, QI_STAGE_FORWARD);
     if (share) {
       // X already holds the zero-padded spectra of these records
-    } else if (p->native_fwd) {
+    } else if (p->native_fwd && native_len_ok(Lf0)) {
       native::RowArgs<T> f{};
       f.Lf = Lf0;
       f.n = n;
@@ -1407,9 +1410,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   QI_REQUIRE(desc->n >= 2 && desc->n <= (1ll << 28), "n = %lld out of range", (long long)desc->n);
   QI_REQUIRE(desc->dtype == QI_F32 || desc->dtype == QI_F64, "bad dtype %d", desc->dtype);
   QI_REQUIRE(desc->engine >= QI_ENGINE_AUTO && desc->engine <= QI_ENGINE_NATIVE, "bad engine %d", desc->engine);
-  if (desc->engine == QI_ENGINE_NATIVE && !(desc->dtype == QI_F32 && is_pow2(desc->n) &&
-                                            (native_len_ok(desc->n) || native_len_ok(2 * desc->n)))) {
-    set_error("native engine: float32 records of 2^19, 2^20 or 2^21 samples only (got n = %lld, dtype %d)",
+  if (desc->engine == QI_ENGINE_NATIVE && !(desc->dtype == QI_F32 && is_pow2(desc->n) && desc->n >= (1 << 18))) {
+    set_error("native engine: float32 records of a power-of-two length >= 2^18 only (got n = %lld, dtype %d)",
               (long long)desc->n, desc->dtype);
     return QI_ERR_UNSUPPORTED;
   }
@@ -1680,9 +1682,16 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
         ngen++;
       }
     }
-    QI_TRY(upload_native_table(p, 2, p->n, bands));
-    p->nat[2].nbands = B;
-    QI_TRY(build_block_stx<float>(p, picks, coef, nullptr));
+    bool two_pass_free = true;  // no band for pass 1 / pass 2 (their transform lengths are 2^20 and 2^21 only)
+    for (const auto& d : bands) two_pass_free = two_pass_free && d.mode >= 2;
+    if (native_len_ok(p->n) || two_pass_free) {
+      QI_TRY(upload_native_table(p, 2, p->n, bands));
+      p->nat[2].nbands = B;
+      QI_TRY(build_block_stx<float>(p, picks, coef, nullptr));
+    } else if (p->d.engine == QI_ENGINE_NATIVE) {
+      set_error("native engine: this Stockwell band table needs the two-pass kernels, which run 2^20 / 2^21 samples only");
+      return QI_ERR_UNSUPPORTED;
+    }  // else: the hipFFT engine runs it (nat[2] stays empty)
   } else if (p->d.engine == QI_ENGINE_NATIVE) {
     set_error("native engine does not support the Stockwell transform at n = %lld", (long long)p->n);
     return QI_ERR_UNSUPPORTED;

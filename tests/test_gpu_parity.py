@@ -459,12 +459,13 @@ def test_fused_cwt_stx_call_matches_separate_calls():
     plan.close()
 
 
-def test_native_stockwell_two_million_samples():
-    """The largest native size: Stockwell transform of 2^21 samples (zoom, block and two-pass bands on a 2^21-point
-    spectrum) against the hipFFT engine."""
+@pytest.mark.parametrize("log2n", [18, 19, 21, 22])
+def test_native_stockwell_other_lengths(log2n):
+    """Stockwell transform at the other power-of-two lengths the native engine takes (its band tables need only the
+    zoom and block engines, which are not tied to the two-pass kernels' 2^20 / 2^21) against the hipFFT engine."""
     from quantum_inferno_amd import _lib
 
-    n, fs, order = 1 << 21, 1000.0, 3
+    n, fs, order = 1 << log2n, 1000.0, 3
     x = torch.from_numpy(orc.synth_chirp(n, fs, 0, 1, np.float32)[None, :]).cuda()
     nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
     ws = engine.TfrPlan.workspace_for(n, nb, np.float32, 1)
