@@ -64,14 +64,22 @@ def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):
     return out
 
 
+_GATHER_BUFFERS = {}
+
+
 def gather_reduced(flat, dst=0, group=None):
-    """Gather equal-sized reduced buffers to `dst`; returns [world, len] there, None elsewhere."""
+    """Gather equal-sized reduced buffers to `dst`; returns [world, len] there, None elsewhere.  The receive buffer is
+    kept between calls (one [world, len] allocation per shape), the ranks' messages land in its rows directly."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return flat.unsqueeze(0)
     world = dist.get_world_size(group)
     if dist.get_rank(group) == dst:
-        bufs = [torch.empty_like(flat) for _ in range(world)]
-        dist.gather(flat, bufs, dst=dst, group=group)
-        return torch.stack(bufs)
+        key = (flat.numel(), flat.dtype, flat.device, world)
+        out = _GATHER_BUFFERS.get(key)
+        if out is None:
+            _GATHER_BUFFERS.clear()
+            out = _GATHER_BUFFERS[key] = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
+        dist.gather(flat, list(out.unbind(0)), dst=dst, group=group)
+        return out
     dist.gather(flat, None, dst=dst, group=group)
     return None
