@@ -285,8 +285,8 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
         half_swap(z[0].x, z[1].x);
         half_swap(z[0].y, z[1].y);
         if (inside && !QI_BDBG(1))
-          *reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) =
-              make_float4(z[0].x, z[0].y, z[1].x, z[1].y);
+          stream_store(reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))),
+                       make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
       }
       if (BITS) {
         half_swap(lg[0], lg[1]);

@@ -22,6 +22,32 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
+// streaming stores of panel data that is never read back by this launch (nontemporal: no allocation in the caches)
+typedef float qi_f2 __attribute__((ext_vector_type(2)));
+typedef float qi_f4 __attribute__((ext_vector_type(4)));
+typedef double qi_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(float2* p, float2 v) {
+#ifdef QI_NO_STREAM_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store((qi_f2){v.x, v.y}, reinterpret_cast<qi_f2*>(p));
+#endif
+}
+__device__ __forceinline__ void stream_store(double2* p, double2 v) {
+#ifdef QI_NO_STREAM_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store((qi_d2){v.x, v.y}, reinterpret_cast<qi_d2*>(p));
+#endif
+}
+__device__ __forceinline__ void stream_store(float4* p, float4 v) {
+#ifdef QI_NO_STREAM_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store((qi_f4){v.x, v.y, v.z, v.w}, reinterpret_cast<qi_f4*>(p));
+#endif
+}
+
 // |z|^2 and scaled power in one fixed instruction form, so that every kernel variant (with or without the
 // coefficient / bits stores) rounds the reductions identically
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       const int c = KIND == 0 ? i + 4 : (KIND == 1 ? ((i + 8) & 15) : i);
       const cplx<T> z = u[brev(c, 4)];
       const uint32_t tt = tb + (uint32_t)i * tstep;
-      if (COEF && !QI_DBG(1)) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+      if (COEF && !QI_DBG(1)) stream_store(reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))), z);
       const T m2 = norm2(z.x, z.y);
       if (BITS) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
       T p = mul_rn(a.power_scale, m2);

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
         z = cmul_rn(z, cmul_rn(P, q));
       }
       const uint32_t tt = tb + (uint32_t)(kZoomD * s);
-      if (COEF) *reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))) = z;
+      if (COEF) stream_store(reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))), z);
       const T m2 = norm2(z.x, z.y);
       if (BITS) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
       const T p = mul_rn(a.power_scale, m2);
