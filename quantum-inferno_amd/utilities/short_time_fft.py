@@ -52,10 +52,11 @@ class TukeyStft:
         self.m_num_mid = self.m_num // 2
         self.scaling = scaling
         win = np.asarray(window, dtype=np.float64)
-        if scaling == "magnitude":  # ShortTimeFFT.scale_to: the window itself carries the factor
-            win = win * (1.0 / abs(np.sum(win)))
+        # ShortTimeFFT.scale_to: the window itself carries the factor (SciPy sums with the builtin, in index order)
+        if scaling == "magnitude":
+            win = win * (1 / abs(sum(win)))
         elif scaling == "psd":
-            win = win * (1.0 / np.sqrt(np.sum(win ** 2) / self.T))
+            win = win * (1 / np.sqrt(sum(win.real ** 2 + win.imag ** 2) / self.T))
         self.win = win
         self.delta_t = self.hop * self.T
         self.f = np.fft.rfftfreq(self.mfft, self.T)

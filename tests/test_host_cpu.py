@@ -128,3 +128,25 @@ def test_stream_chunking_cursor():
     x = np.arange(2 * 5000, dtype=np.float64).reshape(2, 5000)
     got = [(i, s0, v.shape) for i, s0, v in stream.iter_chunks(x, 2048, 1024, first_chunk=1)]
     assert got == [(1, 1024, (2, 2048)), (2, 2048, (2, 2048)), (3, 2952, (2, 2048))]
+
+
+def test_sliding_stft_geometry_matches_scipy():
+    """The host restatement of scipy.signal.ShortTimeFFT's slice geometry and canonical dual window
+    (quantum-inferno_amd/utilities/short_time_fft.py: TukeyStft) against SciPy itself over a sweep of shapes."""
+    import scipy.signal as ss
+
+    from quantum_inferno_amd.utilities import short_time_fft as stf
+
+    for seg, overlap, alpha, scaling in [(256, 128, 0.25, "magnitude"), (200, 150, 0.5, "psd"), (128, 96, 1.0, "magnitude"),
+                                         (64, 1, 0.0, "magnitude"), (33, 11, 0.3, "psd"), (500, 499, 0.25, "magnitude"),
+                                         (16, 8, 0.25, None)]:
+        obj = stf.get_stft_object_tukey(800.0, alpha, seg, overlap, scaling)
+        win = ss.windows.tukey(seg, alpha=alpha)
+        np.testing.assert_array_equal(stf.tukey_window_symmetric(seg, alpha), win)
+        ref = ss.ShortTimeFFT(win=win, hop=seg - overlap, fs=800.0, mfft=obj.mfft, fft_mode="onesided", scale_to=scaling)
+        np.testing.assert_array_equal(obj.win, ref.win)
+        np.testing.assert_array_equal(obj.f, ref.f)
+        assert (obj.p_min, obj.k_min, obj.m_num_mid, obj.delta_t) == (ref.p_min, ref.k_min, ref.m_num_mid, ref.delta_t)
+        for n in (seg, seg + 1, 3 * seg + 7, 4096, 10007):
+            assert obj.p_max(n) == ref.p_max(n) and obj.k_max(n) == ref.k_max(n), (seg, overlap, n)
+        np.testing.assert_array_equal(obj.dual_win, ref.dual_win)
