@@ -984,8 +984,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   int64_t zstat_base[NL] = {}, zgroups[NL] = {}, zoom_stats = 0, zslots = 0;
   const int chunk_z0 = chunk_total;
   if (zoom) {
-    // the levels are separate launches that share their per-time planes: the launch with the most chunks runs first
-    // and writes them, the others add to them
+    // one launch for every level: each (level, chunk) pair is a row of the grid and owns a per-time plane
     for (int g = 0; g < NL; ++g) {
       if (zt.zoom_count[g] <= 0) continue;
       zgroups[g] = native::zoom_groups(n, g);
@@ -993,7 +992,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       if (nc < 1) nc = 1;
       if (nc > zt.zoom_count[g]) nc = zt.zoom_count[g];
       znchunk[g] = nc;
-      if (nc > zplanes) zplanes = nc;
+      zplanes += nc;
       zstat_base[g] = zoom_stats;
       zoom_stats += (int64_t)nc * zgroups[g];
       if (zgroups[g] > zslots) zslots = zgroups[g];
@@ -1228,26 +1227,20 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
       QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
-      int order[NL];
-      for (int g = 0; g < NL; ++g) order[g] = g;
-      std::stable_sort(order, order + NL, [&](int x, int y) { return znchunk[x] > znchunk[y]; });
-      bool planes_written = false;
-      for (int oi = 0; oi < NL; ++oi) {
-        const int g = order[oi];
-        if (znchunk[g] <= 0) continue;
-        int first = 0;
-        for (int q = 0; q < g; ++q) first += zt.zoom_count[q];
-        native::ZoomArgs<T> zc = z;
-        zc.band_first = first;
-        zc.band_count = zt.zoom_count[g];
-        zc.weights = p->d_zoom_w[g][z.lane_off];
-        zc.stat_base = p2_stats + blk_stats + zstat_base[g];
-        zc.time_accumulate = planes_written ? 1 : 0;
-        p->prof.begin(st, QI_STAGE_ZOOM);
-        QI_TRY(native::launch_zoom<T>(zc, g, znchunk[g], ct, st));
-        p->prof.end(QI_STAGE_ZOOM, st);
-        planes_written = true;
+      int first = 0, chunk0 = 0;
+      for (int g = 0; g < NL; ++g) {
+        z.lvl_first[g] = first;
+        z.lvl_count[g] = zt.zoom_count[g];
+        z.lvl_chunk0[g] = chunk0;
+        z.lvl_nchunk[g] = znchunk[g];
+        z.lvl_stat_base[g] = p2_stats + blk_stats + zstat_base[g];
+        z.lvl_weights[g] = p->d_zoom_w[g][z.lane_off];
+        first += zt.zoom_count[g];
+        chunk0 += znchunk[g];
       }
+      p->prof.begin(st, QI_STAGE_ZOOM);
+      QI_TRY(native::launch_zoom<T>(z, ct, st));
+      p->prof.end(QI_STAGE_ZOOM, st);
     }
     if (blocks && !overlap) QI_TRY(launch_blocks(st));
     if (overlap) QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));  // join before the reductions are finalised

@@ -151,13 +151,15 @@ struct ZoomArgs {
   const BandDesc* bands;   // [nbands] device: one-pass descriptors of the zoom bands, ordered by level; for these
                            // bands `edge` = first plane of the band's coarse array, `edge_slot` = its level
   const int32_t* plane_band;       // [planes] device: band (index into `bands`) that owns each coarse plane
-  int32_t band_first, band_count;  // the fine launch's range of `bands` (one level)
-  int32_t time_accumulate;         // add to the per-time planes instead of writing them (later launches of a call)
+  // the fine launch covers every level: blockIdx.y in [lvl_chunk0[g], lvl_chunk0[g] + lvl_nchunk[g]) works on level g,
+  // bands [lvl_first[g], lvl_first[g] + lvl_count[g]) of `bands`, and writes per-time plane chunk_base + blockIdx.y
+  int32_t lvl_first[kZoomLevels], lvl_count[kZoomLevels], lvl_chunk0[kZoomLevels], lvl_nchunk[kZoomLevels];
+  int64_t lvl_stat_base[kZoomLevels];
+  const float* lvl_weights[kZoomLevels];  // [taps][64] interpolation weights of the lanes, per level
   const cplx<T>* X;        // [C][Lf << x_shift] spectra of the records
   int32_t x_shift;         // 1: X is the spectrum of the records zero-padded to twice Lf (bin k of Lf = bin 2k)
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
   cplx<T>* coarse;         // [C][planes][4096]: per band [P][4096], P = M_g / 4096: sample tau = P tau2 + tau1 at [tau1][tau2]
-  const float* weights;    // [taps][64] interpolation weights of the lanes (one table per level and lane offset)
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off
   int64_t tau_off;
@@ -168,7 +170,7 @@ struct ZoomArgs {
   T* time_part;       // [C][chunk_total][n]
   double* part_band;  // [C][panel_bands][nblk]: slot = workgroup index along time
   double* part_stat;  // [C][stat_stride][3]: slot = stat_base + chunk * groups + group
-  int64_t nblk, stat_stride, stat_base;
+  int64_t nblk, stat_stride;
   int32_t chunk_base, chunk_total;
   T power_scale, eps;
 };
@@ -178,7 +180,7 @@ int launch_zoom_gather(const ZoomArgs<T>& a, int max_level, int64_t n_channels, 
 template <typename T>
 int launch_zoom_coarse(const ZoomArgs<T>& a, int max_level, int64_t n_channels, hipStream_t st);  // their 4096-point transforms, in place (qi_block.hip)
 template <typename T>
-int launch_zoom(const ZoomArgs<T>& a, int level, int nchunk, int64_t n_channels, hipStream_t st);
+int launch_zoom(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 
 template <typename T>

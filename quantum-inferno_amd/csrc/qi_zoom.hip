@@ -76,8 +76,12 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
 // Fine stage of one level.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands
 // are at baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
 template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS>
-__global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
+__device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, double (*s_red)[kZoomThreads / kWave],
+                                           double (*s_fin)[kZoomThreads / kWave]) {
   constexpr int NW = kZoomThreads / kWave, S = zoom_span(LEVEL), TAPS = zoom_taps(LEVEL), STEPS = zoom_steps(LEVEL);
+  if ((int64_t)blockIdx.x >= a.n / ((int64_t)kZoomD * STEPS * NW)) return;  // this level has fewer groups along time
+  const int nchunk = a.lvl_nchunk[LEVEL];
+  const float* __restrict__ weights = a.lvl_weights[LEVEL];
   constexpr int HALF = 6, WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
   static_assert(WIN <= 2 * kWave, "the window of one wave must fit two registers of its lanes");
   constexpr bool TWO = WIN > kWave;  // the window spills into a second vector register
@@ -89,15 +93,14 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   const int plog2 = ilog2((int)((a.Lf / kZoomD) / kBlk)) + LEVEL;  // log2 of the planes per band
   float wgt[TAPS];
 #pragma unroll
-  for (int j = 0; j < TAPS; ++j) wgt[j] = a.weights[j * kWave + lane];  // [tap][lane]: coalesced
+  for (int j = 0; j < TAPS; ++j) wgt[j] = weights[j * kWave + lane];  // [tap][lane]: coalesced
   T colp[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) colp[s] = T(0);
   T mx = T(0);
   double plogp = 0.0;
   const uint32_t t_base = step_a * kZoomD + (uint32_t)lane;  // output sample of wave-step s: t_base + 64 s
-  __shared__ double s_red[2][NW];
-  int par = 0;  // double-buffered so that one barrier per band is enough
+  int par = 0;  // s_red is double-buffered so that one barrier per band is enough
 
   // lane i holds coarse sample S (step_a + A) - HALF + i of the band: wave-step s interpolates from lanes s S ..
   // s S + TAPS - 1.  Coarse sample tau = P tau2 + tau1 sits at plane tau1, position tau2 (the coarse stage's layout).
@@ -106,19 +109,19 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   const uint32_t widx = (wtau & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau >> plog2);
   const uint32_t wtau2 = (wtau + (uint32_t)kWave) & mmask;  // window samples 64 .. 127 (wide windows only)
   const uint32_t widx2 = (wtau2 & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau2 >> plog2);
-  const int jj0 = a.band_first + blockIdx.y, jj_end = a.band_first + a.band_count;
+  const int jj0 = a.lvl_first[LEVEL] + chunk, jj_end = a.lvl_first[LEVEL] + a.lvl_count[LEVEL];
   cplx<T> smp_next = mk<T>(T(0), T(0)), smq_next = mk<T>(T(0), T(0));
-  BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.band_first];
+  BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.lvl_first[LEVEL]];
   if (jj0 < jj_end) {
     const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
     smp_next = b[widx];
     if (TWO) smq_next = b[widx2];
   }
-  for (int jj = jj0; jj < jj_end; jj += gridDim.y) {
+  for (int jj = jj0; jj < jj_end; jj += nchunk) {
     const BandDesc bd = bd_next;
     const cplx<T> smp = smp_next, smq = smq_next;
-    if (jj + (int)gridDim.y < jj_end) {
-      bd_next = a.bands[jj + gridDim.y];
+    if (jj + nchunk < jj_end) {
+      bd_next = a.bands[jj + nchunk];
       const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
       smp_next = b[widx];
       if (TWO) smq_next = b[widx2];
@@ -206,13 +209,9 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   for (int s = 0; s < STEPS; ++s) {
     tot += colp[s];
     const uint32_t tt = t_base + (uint32_t)(kZoomD * s);
-    if (time_row) {
-      T* dst = reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T)));
-      *dst = a.time_accumulate ? *dst + colp[s] : colp[s];
-    }
+    if (time_row) *reinterpret_cast<T*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = colp[s];
   }
   if (a.part_stat) {
-    __shared__ double s_fin[3][NW];
     const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
     if (lane == 0) {
       s_fin[0][wv] = r0;
@@ -227,7 +226,8 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
         s1 += s_fin[1][q];
         s2 += s_fin[2][q];
       }
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+      const int64_t groups = a.n / ((int64_t)kZoomD * STEPS * NW);
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.lvl_stat_base[LEVEL] + (int64_t)chunk * groups + blockIdx.x) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;
@@ -235,19 +235,28 @@ __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   }
 }
 
-template <typename T, int LEVEL, bool PHASOR>
+// one launch for every level: blockIdx.y selects (level, chunk of the level's band list)
+template <typename T, bool PHASOR, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
+  __shared__ double s_red[2][kZoomThreads / kWave];
+  __shared__ double s_fin[3][kZoomThreads / kWave];
+  const int y = blockIdx.y;
+  if (y < a.lvl_chunk0[0] + a.lvl_nchunk[0]) zoom_level<T, 0, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[0], s_red, s_fin);
+  else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[1], s_red, s_fin);
+  else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[2], s_red, s_fin);
+  else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[3], s_red, s_fin);
+  else zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], s_red, s_fin);
+}
+
+template <typename T, bool PHASOR>
 int launch_zoom_v(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
   const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
-  if (coef && bits) k_zoom<T, LEVEL, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (coef) k_zoom<T, LEVEL, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
-  else if (bits) k_zoom<T, LEVEL, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
-  else k_zoom<T, LEVEL, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
+  if (coef && bits) k_zoom<T, PHASOR, true, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (coef) k_zoom<T, PHASOR, true, false><<<grid, kZoomThreads, 0, st>>>(a);
+  else if (bits) k_zoom<T, PHASOR, false, true><<<grid, kZoomThreads, 0, st>>>(a);
+  else k_zoom<T, PHASOR, false, false><<<grid, kZoomThreads, 0, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;
-}
-template <typename T, int LEVEL>
-int launch_zoom_t(const ZoomArgs<T>& a, dim3 grid, hipStream_t st) {
-  return a.stx ? launch_zoom_v<T, LEVEL, false>(a, grid, st) : launch_zoom_v<T, LEVEL, true>(a, grid, st);
 }
 
 }  // namespace
@@ -268,23 +277,23 @@ int launch_zoom_gather<float>(const ZoomArgs<float>& a, int max_level, int64_t n
 }
 
 template <>
-int launch_zoom<float>(const ZoomArgs<float>& a, int level, int nchunk, int64_t n_channels, hipStream_t st) {
-  if (a.band_count <= 0) return QI_OK;
-  const int64_t groups = zoom_groups(a.n, level);
-  if (groups < 1 || groups * kZoomD * zoom_steps(level) * (kZoomThreads / kWave) != a.n) {
-    set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
-              kZoomD * zoom_steps(level) * (kZoomThreads / kWave));
-    return QI_ERR_UNSUPPORTED;
+int launch_zoom<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+  int64_t groups = 0;
+  int chunks = 0;
+  for (int g = 0; g < kZoomLevels; ++g) {
+    if (a.lvl_nchunk[g] <= 0) continue;
+    const int64_t gg = zoom_groups(a.n, g);
+    if (gg < 1 || gg * kZoomD * zoom_steps(g) * (kZoomThreads / kWave) != a.n) {
+      set_error("zoom engine: record length %lld is not a multiple of %d samples", (long long)a.n,
+                kZoomD * zoom_steps(g) * (kZoomThreads / kWave));
+      return QI_ERR_UNSUPPORTED;
+    }
+    if (gg > groups) groups = gg;
+    chunks = a.lvl_chunk0[g] + a.lvl_nchunk[g];
   }
-  dim3 grid((unsigned)groups, (unsigned)nchunk, (unsigned)n_channels);
-  switch (level) {
-    case 0: return launch_zoom_t<float, 0>(a, grid, st);
-    case 1: return launch_zoom_t<float, 1>(a, grid, st);
-    case 2: return launch_zoom_t<float, 2>(a, grid, st);
-    case 3: return launch_zoom_t<float, 3>(a, grid, st);
-    case 4: return launch_zoom_t<float, 4>(a, grid, st);
-    default: set_error("zoom engine: level %d out of range", level); return QI_ERR_ARG;
-  }
+  if (chunks <= 0) return QI_OK;
+  dim3 grid((unsigned)groups, (unsigned)chunks, (unsigned)n_channels);
+  return a.stx ? launch_zoom_v<float, false>(a, grid, st) : launch_zoom_v<float, true>(a, grid, st);
 }
 
 // Interpolation weights of lane L for window sample j of a wave-step at `level`: the lane sits x = (L - e) / D coarse
