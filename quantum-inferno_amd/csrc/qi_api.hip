@@ -280,6 +280,7 @@ struct qi_plan {
     native::BlockBand* d_bands = nullptr;  // all reach groups, group by group
     native::BlockItem* d_items = nullptr;  // one per workgroup, most expensive first
     int32_t nitems = 0, nplanes = 0;
+    int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
     int64_t max_blocks = 0;  // partial slots a band row needs
     std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
     void release() {
@@ -297,13 +298,21 @@ struct qi_plan {
   int32_t* d_band_slots[3] = {nullptr, nullptr, nullptr};  // per table kind: partial slots each band's engine writes
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_max_level = 3;  // finest coarse grid the zoom engine may use (level 4 costs more in the coarse stage than two-pass saves)
-  int native_zoom_waves = 2048; // waves a zoom launch should have at least (band chunks are sized for it)
+  int native_zoom_waves = 2048; // native_zoom_wgs = 0: waves each level of a zoom launch should have at least
+  int native_zoom_wgs = 0;      // > 0: workgroups of a zoom launch, dealt to the levels by work (measured: 1.5 % slower than the per-level rule)
   float* d_zoom_w[native::kZoomLevels][2] = {};  // interpolation weights [level][lane offset]
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
   // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
   int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // split bands of the styx bank (atoms longer than the record): zoom engine + edge pieces, see split_taper
+  int native_split = 1;        // 0: such bands stay on the two-pass kernels
+  int64_t native_split_e = 1024;  // taper length in samples (512, 1024 or 2048: the edge pieces' reach group)
+  void* split_bank = nullptr;  // [nsplit][2][kBlk] filter spectra of the edge pieces
+  int32_t* d_split_bands = nullptr;  // [nsplit] panel rows of the split bands
+  std::vector<int32_t> h_split_bands;
+  int32_t nsplit = 0;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
@@ -577,7 +586,7 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
 
 // Support analysis of `count` atom spectra starting at band j0 (rows built in `circular` or linear form).
 int analyse_support(qi_plan* p, int circular, int64_t L, int32_t B, int32_t j0, int32_t count, const double* d_par,
-                    std::vector<double>* sup, hipStream_t st) {
+                    std::vector<double>* sup, hipStream_t st, double taper_e = 0.0) {
   const size_t row64 = (size_t)L * sizeof(double2);
   int64_t chunk = (int64_t)((p->ws_bytes - 4096) / row64);
   if (chunk < 1) {
@@ -591,7 +600,8 @@ int analyse_support(qi_plan* p, int circular, int64_t L, int32_t B, int32_t j0, 
   int rc = QI_OK;
   for (int32_t q = 0; q < count && rc == QI_OK; q += (int32_t)chunk) {
     const int nbk = (count - q < chunk) ? count - q : (int)chunk;
-    rc = launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0 + q, nbk, st);
+    rc = launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, j0 + q, nbk, st,
+                          taper_e);
     if (rc == QI_OK) rc = fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st);
     if (rc == QI_OK) rc = native::launch_band_support(rows, L, nbk, thr2, d_sup + (size_t)q * 3, st);
   }
@@ -616,11 +626,13 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
   double2* rows = reinterpret_cast<double2*>(p->ws);
   size_t q = 0;
   while (q < ids.size()) {
-    // a run of consecutive band ids, at most `chunk` long
+    // a run of consecutive band ids, at most `chunk` long (split bands -- tapered rows -- apart from the others)
     size_t r = q + 1;
-    while (r < ids.size() && ids[r] == ids[r - 1] + 1 && (int64_t)(r - q) < chunk) ++r;
+    const bool tapered = bands[q].add_row != 0;
+    while (r < ids.size() && ids[r] == ids[r - 1] + 1 && (int64_t)(r - q) < chunk && (bands[r].add_row != 0) == tapered) ++r;
     const int nbk = (int)(r - q);
-    QI_TRY(launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, ids[q], nbk, st));
+    QI_TRY(launch_bank_rows(rows, p->n, L, circular, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, ids[q], nbk, st,
+                            tapered ? (double)p->native_split_e : 0.0));
     QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
     for (int jj = 0; jj < nbk; ++jj) {
       const native::BandDesc& d = bands[q + jj];
@@ -696,6 +708,11 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     const int32_t nchunk = (int32_t)ceil_div(count, p->native_blk_bands);
     const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
     if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
+    if (getenv("QI_NATIVE_VERBOSE"))
+      fprintf(stderr, "[qi plan] block table %d, reach <= %d: %d bands (%d analytic) in %d workgroups x %lld blocks\n", kind,
+              256 * wqs[g], count,
+              (int)std::count_if(list.begin() + first, list.end(), [](const native::BlockBand& b) { return b.analytic != 0; }),
+              nchunk, (long long)nblocks);
     for (int32_t q = first; q < (int32_t)list.size(); ++q) bt.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
     for (int32_t c = 0; c < nchunk; ++c) {
       const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
@@ -717,6 +734,20 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
                    [](const native::BlockItem& x, const native::BlockItem& y) { return x.band_count > y.band_count; });
   for (size_t i = 0; i < items.size(); ++i) items[i].stat_slot = (int32_t)i;
   bt.nitems = (int32_t)items.size();
+  if (kind == 0 && p->nsplit > 0) {
+    // the edge items of the split bands ride at the end of the launch (light items: they fill its tail); each split
+    // band has a per-time plane and one partial slot per block like the other bands of the launch
+    const int wq = (int)(p->native_split_e / 512);
+    const int64_t nblocks = ceil_div(p->n, native::block_valid(wq));
+    if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
+    for (int32_t sb = 0; sb < p->nsplit; ++sb) {
+      for (int64_t b = 0; b < nblocks; ++b)
+        items.push_back({-wq, (int32_t)b, sb, 0, bt.nplanes, (int32_t)items.size()});
+      bt.nplanes += 1;
+      bt.h_bands.push_back({p->h_split_bands[sb], (int32_t)nblocks});
+    }
+    bt.nedge_items = (int32_t)items.size() - bt.nitems;
+  }
   QI_HIP(hipMalloc((void**)&bt.d_bands, list.size() * sizeof(native::BlockBand)));
   QI_HIP(hipMemcpy(bt.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
   QI_HIP(hipMalloc((void**)&bt.d_items, items.size() * sizeof(native::BlockItem)));
@@ -804,7 +835,7 @@ int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
 template <typename T>
 int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B, const std::vector<int32_t>& ids,
                       const std::vector<double>& sup /*[ids][3]*/, const std::vector<int32_t>& edge_w,
-                      const double* d_par, hipStream_t st) {
+                      const double* d_par, hipStream_t st, const std::vector<int32_t>& add_row = {}) {
   std::vector<native::BandDesc> bands(ids.size());
   int64_t compact = 0;
   int32_t ngen = 0;
@@ -816,6 +847,7 @@ int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B,
     d.out_band = ids[q];
     d.edge = edge_w.empty() ? 0 : edge_w[q];
     d.edge_slot = (int32_t)q;  // the edge list is in the order of `ids`
+    d.add_row = add_row.empty() ? 0 : add_row[q];
     const int zc = zoom_class(p, table, L, len);
     if (zc >= 0 || (len > 0 && len <= p->native_kmax)) {
       d.mode = zc >= 0 ? 2 + zc : 0;  // 0: one-pass loader of pass 2; 2 + c: zoom engine, class c
@@ -882,9 +914,73 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
       keep.push_back(j);
     }
   }
+  // Bands left for the two-pass kernels because the reference cuts their atoms off at |x| = n / 2 (a spectrum with
+  // 1 / k side lobes): with the last `e` samples before the cut tapered away the spectrum is narrow enough for the
+  // zoom engine; what the taper removed is a pair of e-tap filters at lags +-n / 2 (k_block_edge), added back by the
+  // zoom kernel.
+  std::vector<int32_t> split;
+  if (bank == QI_BANK_STYX) {
+    if (p->split_bank) (void)hipFree(p->split_bank);
+    if (p->d_split_bands) (void)hipFree(p->d_split_bands);
+    p->split_bank = nullptr;
+    p->d_split_bands = nullptr;
+    p->h_split_bands.clear();
+    p->nsplit = 0;
+  }
+  const int64_t se = p->native_split_e;
+  if (bank == QI_BANK_STYX && p->native_split && can_block && !picks.empty() &&  // (their edge items ride in the block launch)
+      (se == 512 || se == 1024 || se == 2048) && n >= 8 * se) {
+    for (int32_t j : keep) {
+      const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
+      const int64_t len = hi >= lo ? hi - lo + 1 : 0;
+      if (zoom_class(p, bank, L, len) >= 0 || (len > 0 && len <= p->native_kmax)) continue;
+      std::vector<double> part;
+      QI_TRY(analyse_support(p, 0, L, B, j, 1, d_par, &part, st, (double)se));
+      const int64_t tlo = (int64_t)part[1], thi = (int64_t)part[2];
+      const int64_t tlen = thi >= tlo ? thi - tlo + 1 : 0;
+      if (getenv("QI_NATIVE_VERBOSE"))
+        fprintf(stderr, "[qi plan] band %d: support %lld bins as the reference cuts it, %lld bins tapered over %lld samples\n",
+                j, (long long)len, (long long)tlen, (long long)se);
+      if (zoom_class(p, bank, L, tlen) < 0) continue;
+      std::copy(part.begin(), part.end(), sup.begin() + 3 * j);
+      split.push_back(j);
+    }
+  }
   std::vector<double> sup_keep;
-  for (int32_t j : keep) sup_keep.insert(sup_keep.end(), sup.begin() + 3 * j, sup.begin() + 3 * j + 3);
-  QI_TRY(make_native_table<T>(p, bank, circular, L, B, keep, sup_keep, {}, d_par, st));
+  std::vector<int32_t> add_row;
+  for (int32_t j : keep) {
+    sup_keep.insert(sup_keep.end(), sup.begin() + 3 * j, sup.begin() + 3 * j + 3);
+    const auto it = std::find(split.begin(), split.end(), j);
+    add_row.push_back(it == split.end() ? 0 : (int32_t)(it - split.begin()) + 1);
+  }
+  QI_TRY(make_native_table<T>(p, bank, circular, L, B, keep, sup_keep, {}, d_par, st, add_row));
+  if (!split.empty()) {
+    // filter spectra of the edge pieces: taps in float64, transformed, scaled by 1 / 4096
+    const size_t rows = split.size() * 2;
+    if (p->ws_bytes < rows * native::kBlk * sizeof(double2) + 4096) {
+      set_error("workspace too small for the taps of the split bands");
+      return QI_ERR_NOMEM;
+    }
+    double2* taps = reinterpret_cast<double2*>(p->ws);
+    QI_HIP(hipMalloc((void**)&p->d_split_bands, split.size() * sizeof(int32_t)));
+    int32_t* d_ids = p->d_split_bands;
+    int rc = hipMemcpy(d_ids, split.data(), split.size() * sizeof(int32_t), hipMemcpyHostToDevice) == hipSuccess
+                 ? QI_OK : QI_ERR_HIP;
+    if (rc == QI_OK)
+      rc = native::launch_block_taps_edge(taps, (int)(se / 2), n, (double)se, d_par, B, d_ids, (int)split.size(), st);
+    if (rc == QI_OK) rc = fft_c2c<double>(p->fft, taps, native::kBlk, (int64_t)rows, HIPFFT_FORWARD, st);
+    if (rc == QI_OK && hipMalloc(&p->split_bank, rows * native::kBlk * sizeof(cplx<T>)) != hipSuccess) rc = QI_ERR_NOMEM;
+    if (rc == QI_OK)
+      rc = launch_bank_convert<T>(taps, static_cast<cplx<T>*>(p->split_bank), (int64_t)rows * native::kBlk, 0,
+                                  1.0 / (double)native::kBlk, st);
+    (void)hipStreamSynchronize(st);
+    if (rc != QI_OK) {
+      if (rc == QI_ERR_HIP) set_error("building the edge pieces of the split bands failed");
+      return rc;
+    }
+    p->nsplit = (int32_t)split.size();
+    p->h_split_bands = split;
+  }
   p->nat[bank].nbands = B;  // the table's panel has all B rows even when some are produced by table 3 / the block engine
   if (bank == QI_BANK_STYX) {
     std::stable_sort(picks.begin(), picks.end(), [](const BlockPick& x, const BlockPick& y) { return x.wq < y.wq; });
@@ -973,7 +1069,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   int64_t blk_stats = 0, blk_slots = 0;
   if (blocks) {
     chunk_total += bt.nplanes;
-    blk_stats = bt.nitems;
+    blk_stats = bt.nitems + bt.nedge_items;
     blk_slots = bt.max_blocks;
   }
   // zoom engine launch (narrow bands of the main table): its chunks come last
@@ -985,18 +1081,59 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const int chunk_z0 = chunk_total;
   if (zoom) {
     // one launch for every level: each (level, chunk) pair is a row of the grid and owns a per-time plane
+    // All workgroups of the launch should be resident at once (native_zoom_wgs of them) and finish together: every
+    // level starts with one row, then the level whose rows carry the most work per workgroup gets the next one
+    // (per band: a little more at the higher levels, half at level 3 and up where a workgroup covers half the samples).
+    const double level_cost[NL] = {1.0, 1.08, 1.25, 0.75, 1.0};
+    int64_t wgs = 0;
     for (int g = 0; g < NL; ++g) {
       if (zt.zoom_count[g] <= 0) continue;
       zgroups[g] = native::zoom_groups(n, g);
-      int nc = (int)ceil_div(p->native_zoom_waves, 4 * zgroups[g] * C);
-      if (nc < 1) nc = 1;
-      if (nc > zt.zoom_count[g]) nc = zt.zoom_count[g];
-      znchunk[g] = nc;
-      zplanes += nc;
+      znchunk[g] = 1;
+      wgs += zgroups[g] * C;
+    }
+    if (p->native_zoom_wgs > 0) {
+      for (;;) {
+        int best = -1;
+        double best_load = 0.0;
+        for (int g = 0; g < NL; ++g) {
+          if (zt.zoom_count[g] <= 0 || znchunk[g] >= zt.zoom_count[g]) continue;
+          const double load = level_cost[g] * (double)ceil_div(zt.zoom_count[g], znchunk[g]);
+          if (load > best_load) {
+            best_load = load;
+            best = g;
+          }
+        }
+        if (best < 0 || wgs + zgroups[best] * C > p->native_zoom_wgs) break;
+        // (a level that cannot grow any more but carries the largest load ends the search: more rows elsewhere would
+        // not shorten the launch)
+        bool is_max = true;
+        for (int g = 0; g < NL; ++g)
+          if (zt.zoom_count[g] > 0 && level_cost[g] * (double)ceil_div(zt.zoom_count[g], znchunk[g]) > best_load) is_max = false;
+        if (!is_max) break;
+        znchunk[best] += 1;
+        wgs += zgroups[best] * C;
+      }
+    } else {
+      for (int g = 0; g < NL; ++g) {
+        if (zt.zoom_count[g] <= 0) continue;
+        int nc = (int)ceil_div(p->native_zoom_waves, 4 * zgroups[g] * C);
+        if (nc < 1) nc = 1;
+        if (nc > zt.zoom_count[g]) nc = zt.zoom_count[g];
+        znchunk[g] = nc;
+      }
+    }
+    for (int g = 0; g < NL; ++g) {
+      if (zt.zoom_count[g] <= 0) continue;
+      zplanes += znchunk[g];
       zstat_base[g] = zoom_stats;
-      zoom_stats += (int64_t)nc * zgroups[g];
+      zoom_stats += (int64_t)znchunk[g] * zgroups[g];
       if (zgroups[g] > zslots) zslots = zgroups[g];
     }
+    if (getenv("QI_NATIVE_VERBOSE"))
+      fprintf(stderr, "[qi run] zoom launch of table %d: bands per level %d %d %d %d %d in rows %d %d %d %d %d\n", kind,
+              zt.zoom_count[0], zt.zoom_count[1], zt.zoom_count[2], zt.zoom_count[3], zt.zoom_count[4], znchunk[0],
+              znchunk[1], znchunk[2], znchunk[3], znchunk[4]);
     chunk_total += zplanes;
   }
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
@@ -1036,7 +1173,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
   const size_t e_zc = zoom ? (size_t)zt.zoom_planes * native::kBlk * sizeof(cplx<T>) : 0;
-  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_zc;
+  const int32_t nsplit = kind == 0 ? p->nsplit : 0;  // split bands: the zoom launch hands its part to the block launch
+  const size_t e_add = (size_t)nsplit * n * sizeof(cplx<T>);
+  const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_zc + e_add;
   if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
               per_chan + 4096);
@@ -1073,8 +1212,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   T* edge_time = reinterpret_cast<T*>(carve(e_et));
   cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
   cplx<T>* zcoarse = e_zc ? reinterpret_cast<cplx<T>*>(carve(e_zc)) : nullptr;
+  cplx<T>* zadd = e_add ? reinterpret_cast<cplx<T>*>(carve(e_add)) : nullptr;
 
-  const bool overlap = blocks && p->native_overlap;
+  const bool overlap = blocks && p->native_overlap && nsplit == 0;  // (edge items need the zoom launch's output)
   if (overlap && !p->side) {
     QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
     QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -1086,6 +1226,11 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       native::BlockArgs<T> b{};
       b.n = n;
       b.nitems = bt.nitems;
+      b.nedge_items = bt.nedge_items;
+      b.nsplit = nsplit;
+      b.edge_band = p->d_split_bands;
+      b.edge_bank = static_cast<const cplx<T>*>(p->split_bank);
+      b.edge_part = zadd;
       b.panel_bands = (int32_t)B;
       b.items = bt.d_items;
       b.bands = bt.d_bands;
@@ -1226,6 +1371,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
       QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
       QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
+      z.split_part = zadd;
+      z.split_rows = nsplit;
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
       int first = 0, chunk0 = 0;
       for (int g = 0; g < NL; ++g) {
@@ -1242,6 +1389,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(native::launch_zoom<T>(z, ct, st));
       p->prof.end(QI_STAGE_ZOOM, st);
     }
+    // (the edge items of the block launch finish the split bands the zoom launch began: it comes after it)
     if (blocks && !overlap) QI_TRY(launch_blocks(st));
     if (overlap) QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));  // join before the reductions are finalised
     p->prof.begin(st, QI_STAGE_EPILOGUE);
@@ -1442,9 +1590,12 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -1515,6 +1666,8 @@ int qi_plan_destroy(qi_plan* p) {
     for (auto* w : wc)
       if (w) (void)hipFree(w);
   if (p->d_edge) (void)hipFree(p->d_edge);
+  if (p->split_bank) (void)hipFree(p->split_bank);
+  if (p->d_split_bands) (void)hipFree(p->d_split_bands);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);

@@ -351,6 +351,99 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
   }
 }
 
+// Edge item of a split band (see the note on split bands in qi_native.hpp) for output block it.block: the two
+// pieces read the record n/2 - W samples after / before the output block (zero outside the record; a piece whose 4096
+// input samples all lie outside is skipped), their filtered spectra are summed and transformed back once; the zoom
+// engine's part of the band is added and the band is finished like any block band (panel rows, reductions).
+template <typename T, int WQ, bool COEF, bool BITS>
+__device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
+                                          const cplx<T>* __restrict__ tw256, cplx<T> w) {
+  constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
+  const int64_t n = a.n, ch = blockIdx.z, blk = it.block;
+  const int sb = it.band_first, out_band = a.edge_band[sb];
+  const int64_t t0 = blk * V - W;  // outputs [t0 + W, t0 + W + V)
+  const T* __restrict__ sig = a.sig + ch * n;
+  const cplx<T>* __restrict__ bank = a.edge_bank + (int64_t)sb * 2 * kBlk;
+  // the zoom engine's part of this thread's outputs, requested first
+  const cplx<T>* __restrict__ part = a.edge_part + (ch * a.nsplit + sb) * n;
+  const uint32_t tb = (uint32_t)(t0 + W + col);
+  cplx<T> z0[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const uint32_t t = tb + 256u * (uint32_t)i;
+    z0[i] = t < (uint32_t)n ? part[t] : mk<T>(T(0), T(0));
+  }
+  cplx<T> acc[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) acc[b] = mk<T>(T(0), T(0));
+  for (int piece = 0; piece < 2; ++piece) {
+    const int64_t in0 = t0 + (piece == 0 ? n / 2 - W : -(n / 2 - W));
+    if (in0 >= n || in0 + kBlk <= 0) continue;  // the same for every thread of the workgroup
+    cplx<T> S[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int64_t t = in0 + col + 256 * b;
+      S[b] = mk<T>((t >= 0 && t < n) ? sig[t] : T(0), T(0));
+    }
+    fft4096<T, -1>(S, buf, tw256, w, tid, col);
+    const cplx<T>* __restrict__ H = bank + (int64_t)piece * kBlk + col;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const cplx<T> y = cmul(S[brev(b, 4)], H[256 * b]);
+      acc[b].x += y.x;
+      acc[b].y += y.y;
+    }
+  }
+  fft4096<T, 1>(acc, buf, tw256, w, tid, col);
+  const int64_t orow = ((int64_t)ch * a.panel_bands + out_band) * n;
+  cplx<T>* __restrict__ coef_row = a.coef ? a.coef + orow : nullptr;
+  T* __restrict__ bits_row = a.bits ? a.bits + orow : nullptr;
+  T* __restrict__ time_row = a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + it.plane) * n : nullptr;
+  T rowacc = T(0), pl = T(0), mx = T(0);
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const uint32_t t = tb + 256u * (uint32_t)i;
+    const bool inside = t < (uint32_t)n;
+    cplx<T> z = acc[brev(i + WQ, 4)];
+    z.x += z0[i].x;
+    z.y += z0[i].y;
+    const T m2 = norm2(z.x, z.y);
+    if (COEF && inside) stream_store(coef_row + t, z);
+    if (BITS && inside) bits_row[t] = log2_t(sqrt_t(m2) + a.eps);
+    const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
+    if (time_row && inside) time_row[t] = p;
+    rowacc += p;
+    mx = p > mx ? p : mx;
+    pl += plog2p(p);
+  }
+  const double r0 = wave_max((double)mx), r1 = wave_sum((double)rowacc), r2 = wave_sum((double)pl);
+  __syncthreads();  // buf is free
+  double* fin = reinterpret_cast<double*>(buf);
+  if (lane == 0) {
+    fin[wv] = r0;
+    fin[NW + wv] = r1;
+    fin[2 * NW + wv] = r2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < NW; ++q) {
+      m = fin[q] > m ? fin[q] : m;
+      s1 += fin[NW + q];
+      s2 += fin[2 * NW + q];
+    }
+    if (a.part_band) a.part_band[((int64_t)ch * a.panel_bands + out_band) * a.nblk + blk] = s1;
+    if (a.part_stat) {
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + it.stat_slot) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
+    }
+  }
+}
+
 template <typename T, bool DEMOD, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T> a) {
   __shared__ cplx<T> buf[16 * kBlkPad];
@@ -371,6 +464,17 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
     w = mk<T>((T)c, (T)s);
   }
   const BlockItem it = a.items[blockIdx.x];
+  if (it.wq < 0) {
+    // edge item of a split band (styx bank): light items at the end of the list, they fill the tail of the launch
+    if constexpr (!DEMOD) {
+      switch (-it.wq) {
+        case 1: edge_item<T, 1, COEF, BITS>(a, it, buf, tw256, w); break;
+        case 2: edge_item<T, 2, COEF, BITS>(a, it, buf, tw256, w); break;
+        default: edge_item<T, 4, COEF, BITS>(a, it, buf, tw256, w); break;
+      }
+    }
+    return;
+  }
   switch (it.wq) {
     case 1: block_item<T, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
     case 2: block_item<T, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
@@ -431,6 +535,37 @@ __global__ void k_block_taps_gabor(double2* __restrict__ g, int w, const double*
       v = make_double2(env * c, -env * s);  // conj(psi)
     }
     row[m] = v;
+  }
+}
+
+
+// taps of the edge pieces of a split band as 4096-point circular-convolution kernels (the layout of
+// k_block_taps_gabor): row 2 s + piece, g[(-v) mod 4096] = (1 - taper(x)) conj(psi(x)), x = u + 1/2,
+// u = centre_piece + v, centre = +-(n/2 - w), -w <= v < w
+__global__ void k_block_taps_edge(double2* __restrict__ g, int w, int64_t n, double taper_e,
+                                  const double* __restrict__ par, int nb_total, const int32_t* __restrict__ ids) {
+  const int j = ids[blockIdx.y >> 1], piece = blockIdx.y & 1;
+  const double p_re = par[j], p_im = par[nb_total + j], omega = par[2 * nb_total + j], amp = par[3 * nb_total + j];
+  double2* row = g + (int64_t)blockIdx.y * kBlk;
+  const int64_t centre = piece == 0 ? n / 2 - w : -(n / 2 - w);
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < kBlk; m += gridDim.x * blockDim.x) {
+    int v;
+    bool on = true;
+    if (m <= w) v = -m;
+    else if (m > kBlk - w) v = kBlk - m;
+    else { v = 0; on = false; }
+    const int64_t u = centre + v;
+    if (u < -(n / 2) || u >= n / 2) on = false;  // the atom has n samples
+    double2 val = make_double2(0.0, 0.0);
+    if (on) {
+      const double x = (double)u + 0.5;
+      const double env = (1.0 - split_taper(x, n, taper_e)) * amp * exp(-p_re * x * x);
+      const double ph = omega * x - p_im * x * x;
+      double s, c;
+      sincos(ph, &s, &c);
+      val = make_double2(env * c, -env * s);  // conj(psi)
+    }
+    row[m] = val;
   }
 }
 
@@ -495,8 +630,8 @@ int block_valid(int wq) { return kBlk - 512 * wq; }
 
 template <>
 int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st) {
-  if (a.nitems <= 0) return QI_OK;
-  dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
+  if (a.nitems + a.nedge_items <= 0) return QI_OK;
+  dim3 grid((unsigned)(a.nitems + a.nedge_items), 1, (unsigned)n_channels);
   return demod ? launch_block_v<float, true>(a, grid, st) : launch_block_v<float, false>(a, grid, st);
 }
 
@@ -514,6 +649,14 @@ int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total
                             hipStream_t st) {
   dim3 grid(4, (unsigned)count);
   k_block_taps_gabor<<<grid, 256, 0, st>>>(g, w, d_par, nb_total, d_ids);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+int launch_block_taps_edge(double2* g, int w, int64_t n, double taper_e, const double* d_par, int nb_total,
+                           const int32_t* d_ids, int count, hipStream_t st) {
+  dim3 grid(4, (unsigned)(2 * count));
+  k_block_taps_edge<<<grid, 256, 0, st>>>(g, w, n, taper_e, d_par, nb_total, d_ids);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

@@ -91,7 +91,7 @@ template <typename T>
 int launch_pack_pad(const T* sig, cplx<T>* X, int64_t C, int64_t n, int64_t L, hipStream_t st);
 
 int launch_bank_rows(double2* rows, int64_t n, int64_t L, int circular, const double* p_re, const double* p_im,
-                     const double* omega, const double* amp, int j0, int nb, hipStream_t st);
+                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e = 0.0);
 template <typename T>
 int launch_bank_convert(const double2* F, cplx<T>* bank, int64_t count, int conj, double scale, hipStream_t st);
 

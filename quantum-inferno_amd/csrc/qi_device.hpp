@@ -73,5 +73,16 @@ __device__ __forceinline__ double fast_exp2(double v) { return exp2(v); }
 __device__ __forceinline__ float exp2_t(float v) { return exp2f(v); }
 __device__ __forceinline__ double exp2_t(double v) { return exp2(v); }
 
+// Split of an atom that is longer than the record (styx bank: the reference truncates it at |x| = n / 2,
+// styx_cwt.py:113-144): atom = taper * atom + (1 - taper) * atom.  The taper is 1 up to `e` samples before the
+// truncation and falls to 0 (4e-11) at it as a Gaussian distribution function (+-6.5 standard deviations over `e`
+// samples): the first part has a narrow spectrum (zoom engine), the second is two pieces of `e` taps at lags +-n / 2
+// (k_block_edge).  x = sample position relative to the atom's centre.
+__device__ __forceinline__ double split_taper(double x, int64_t n, double e) {
+  const double r = (0.5 * (double)n - fabs(x)) / e;
+  if (r >= 1.5) return 1.0;
+  return 0.5 * erfc(-(r - 0.5) * (13.0 * 0.70710678118654752440));
+}
+
 
 }  // namespace qi

@@ -20,7 +20,7 @@ __global__ void k_pack_pad(const T* __restrict__ sig, cplx<T>* __restrict__ X, i
 // (the operand scipy.signal.fftconvolve receives, styx_cwt.py:195-196); circular mode the atom itself.
 __global__ void k_bank_rows(double2* __restrict__ rows, int64_t n, int64_t L, int circular,
                             const double* __restrict__ p_re, const double* __restrict__ p_im,
-                            const double* __restrict__ omega, const double* __restrict__ amp, int j0) {
+                            const double* __restrict__ omega, const double* __restrict__ amp, int j0, double taper_e) {
   int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int jj = blockIdx.y;
   int j = j0 + jj;
@@ -30,6 +30,7 @@ __global__ void k_bank_rows(double2* __restrict__ rows, int64_t n, int64_t L, in
     int64_t k = circular ? m : (n - 1 - m);
     double x = (double)k - 0.5 * (double)(n - 1);
     double g = amp[j] * exp(-p_re[j] * x * x);
+    if (taper_e > 0.0) g *= split_taper(x, n, taper_e);  // the zoom-engine part of a split band
     double ph = omega[j] * x - p_im[j] * x * x;
     double s, c;
     sincos(ph, &s, &c);
@@ -366,9 +367,9 @@ int launch_pack_pad(const T* sig, cplx<T>* X, int64_t C, int64_t n, int64_t L, h
 }
 
 int launch_bank_rows(double2* rows, int64_t n, int64_t L, int circular, const double* p_re, const double* p_im,
-                     const double* omega, const double* amp, int j0, int nb, hipStream_t st) {
+                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e) {
   dim3 g((unsigned)ceil_div(L, 256), (unsigned)nb);
-  k_bank_rows<<<g, 256, 0, st>>>(rows, n, L, circular, p_re, p_im, omega, amp, j0);
+  k_bank_rows<<<g, 256, 0, st>>>(rows, n, L, circular, p_re, p_im, omega, amp, j0, taper_e);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

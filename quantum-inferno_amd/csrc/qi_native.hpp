@@ -17,6 +17,8 @@ struct BandDesc {
   int32_t bank_row;  // general Gabor bands: row of the full-spectrum bank
   int32_t edge;      // circularly evaluated short-atom band: samples at each record end fixed by k_edge_fix
   int32_t edge_slot; // index of that band in the edge list (rows of RowArgs::edge_z)
+  int32_t add_row;   // zoom engine, split band: 1 + its row of ZoomArgs::split_part (0: an ordinary band)
+  int32_t pad_;
   int64_t src_off;   // pruned Gabor bands: offset of H[k_lo] in the compact bank
   int64_t shift;     // Stockwell: shift index idx_j
   double coef;       // Stockwell: window coefficient (exp2(-(coef k)^2))
@@ -95,7 +97,8 @@ struct BlockBand {
   float kappa_frac, cw, amp;
 };
 struct BlockItem {  // one workgroup of the block launch
-  int32_t wq;          // reach group: taps within 256 * wq samples
+  int32_t wq;          // reach group: taps within 256 * wq samples; negative: the edge pieces (reach group -wq) of
+                       // split band `band_first` for output block `block` (see EdgeSplitArgs)
   int32_t block;       // block index: outputs [block * V, (block + 1) * V), V = kBlk - 512 wq
   int32_t band_first, band_count;  // its bands in BlockArgs::bands
   int32_t plane;       // time_part plane (relative to chunk_base) it writes
@@ -105,7 +108,11 @@ template <typename T>
 struct BlockArgs {
   int64_t n;
   int32_t nitems, panel_bands;
-  const BlockItem* items;  // [nitems] device, most expensive first
+  int32_t nedge_items, nsplit;  // edge items of the split bands, after the nitems band items
+  const int32_t* edge_band;     // [nsplit] device: panel row of each split band
+  const cplx<T>* edge_bank;     // [nsplit][2][kBlk]
+  const cplx<T>* edge_part;     // [C][nsplit][n]: the zoom engine's part of the split bands
+  const BlockItem* items;  // [nitems + nedge_items] device, most expensive first
   const BlockBand* bands;  // device, all reach groups
   const cplx<T>* bank;     // [rows][kBlk], scaled by 1 / kBlk
   const T* sig;            // [C][n]
@@ -129,6 +136,15 @@ int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);
 int launch_stx_window_row(double2* row, int64_t n, double coef, hipStream_t st);
 int launch_block_rotate_rows(double2* rows, int count, hipStream_t st);
+
+// Split bands (atoms longer than the record, see split_taper in qi_device.hpp): the zoom engine produces the tapered
+// part of band s into part[c][s][t]; the edge items of the block launch (BlockItem::wq < 0) add
+//   sum_piece sum_|v|<=W sig[t + centre_piece + v] taps_piece(v),  centre = +-(n/2 - W), W = 256 wq,
+// taps = (1 - taper) conj(psi) at lags [n/2 - 2W, n/2) and [-n/2, -n/2 + 2W) given as two 4096-point filter spectra
+// bank[s][piece][4096] (scaled by 1 / 4096), by overlap-save like the band items, and finish the band (panel rows,
+// reductions).
+int launch_block_taps_edge(double2* g, int w, int64_t n, double taper_e, const double* d_par, int nb_total,
+                           const int32_t* d_ids, int count, hipStream_t st);
 
 // ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
 // A band with K occupied bins is assigned the coarsest grid "level" g on which it is oversampled >= 4 times:
@@ -159,6 +175,8 @@ struct ZoomArgs {
   const cplx<T>* X;        // [C][Lf << x_shift] spectra of the records
   int32_t x_shift;         // 1: X is the spectrum of the records zero-padded to twice Lf (bin k of Lf = bin 2k)
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
+  cplx<T>* split_part;     // [C][split_rows][n]: the split bands (BandDesc::add_row) leave their samples here, see k_zoom
+  int32_t split_rows;
   cplx<T>* coarse;         // [C][planes][4096]: per band [P][4096], P = M_g / 4096: sample tau = P tau2 + tau1 at [tau1][tau2]
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off

@@ -138,8 +138,13 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, doub
       Q = mk<T>((T)c, (T)s);
     }
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * a.n;
-    char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+    // split band (bd.add_row): this is only the tapered part of its atom -- the samples go to row add_row - 1 of
+    // split_part and count for nothing here; the edge items of the block launch add their part and finish the band
+    const bool part = bd.add_row != 0;
+    char* __restrict__ coef_row = reinterpret_cast<char*>(
+        part ? a.split_part + ((int64_t)ch * a.split_rows + (bd.add_row - 1)) * a.n : (a.coef ? a.coef + orow : nullptr));
     char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    const T pscale = part ? T(0) : a.power_scale;
     uint32_t tb = t_base;
     asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
     T rowacc = T(0), pl = T(0);
@@ -178,10 +183,10 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, doub
         z = cmul_rn(z, cmul_rn(P, q));
       }
       const uint32_t tt = tb + (uint32_t)(kZoomD * s);
-      if (COEF) stream_store(reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))), z);
+      if (COEF || part) stream_store(reinterpret_cast<cplx<T>*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))), z);
       const T m2 = norm2(z.x, z.y);
       if (BITS) *reinterpret_cast<T*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = log2_t(sqrt_t(m2) + a.eps);
-      const T p = mul_rn(a.power_scale, m2);
+      const T p = mul_rn(pscale, m2);
       colp[s] += p;
       rowacc += p;
       mx = p > mx ? p : mx;
@@ -193,7 +198,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, doub
       const double r = wave_sum((double)rowacc);
       if (lane == 0) s_red[par][wv] = r;
       __syncthreads();
-      if (tid == 0) {
+      if (tid == 0 && !part) {
         double t = 0.0;
         for (int q = 0; q < NW; ++q) t += s_red[par][q];
         a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.nblk + blockIdx.x] = t;
