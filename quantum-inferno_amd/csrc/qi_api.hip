@@ -468,9 +468,9 @@ bool native_wanted(const qi_plan* p, int kind) {
   if (p->d.engine == QI_ENGINE_HIPFFT || p->d.dtype != QI_F32) return false;
   const int64_t Lf = kind == 0 ? p->L : p->n;
   if (is_pow2(p->n) && native_len_ok(Lf)) return true;
-  // Stockwell tables usually have no band for the two-pass kernels (exact Gaussian windows: every band is a zoom or a
-  // block band), and those two engines take any power-of-two length from 2^18: the table build decides
-  return kind == 2 && is_pow2(p->n) && p->n >= (1 << 18) && p->n <= (1ll << 26);
+  // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
+  // band), and those engines take any power-of-two length from 2^18: the table build decides
+  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 18) && Lf <= (1ll << 26);
 }
 
 // Order the bands into launch groups: the wide bands are dealt out `native_group` per group (all in one group when
@@ -1692,13 +1692,10 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     p->bank[bank] = nullptr;
     p->nb[bank] = 0;
   }
-  const bool use_native = native_wanted(p, bank);
-  if (!use_native) {
-    if (p->d.engine == QI_ENGINE_NATIVE) {
-      set_error("native engine does not support this bank at n = %lld", (long long)p->n);
-      return QI_ERR_UNSUPPORTED;
-    }
-    QI_HIP(hipMalloc(&p->bank[bank], (size_t)B * L * esz));
+  bool use_native = native_wanted(p, bank);
+  if (!use_native && p->d.engine == QI_ENGINE_NATIVE) {
+    set_error("native engine does not support this bank at n = %lld", (long long)p->n);
+    return QI_ERR_UNSUPPORTED;
   }
   p->nat[bank].release();
   if (bank == QI_BANK_STYX) p->blk[0].release();
@@ -1718,11 +1715,32 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     set_error("hipMemcpy of band parameters failed");
     rc = QI_ERR_HIP;
   }
-  if (rc == QI_OK) {
-    if (use_native)
-      rc = build_native_bank<float>(p, bank, B, d_par, host.data(), st);
-    else
+  if (rc == QI_OK && use_native) {
+    rc = build_native_bank<float>(p, bank, B, d_par, host.data(), st);
+    // The zoom and block engines take any power-of-two record from 2^18 samples; the two-pass kernels run
+    // 2^20 / 2^21-point transforms only.  A table that still has bands for them at another length goes to the hipFFT engine.
+    if (rc == QI_OK && !native_len_ok(L) && !p->nat[bank].h_rows.empty()) {
+      (void)hipStreamSynchronize(st);
+      p->nat[bank].release();
+      if (bank == QI_BANK_STYX) {
+        p->blk[0].release();
+        p->nat[3].release();
+        p->nsplit = 0;
+      }
+      use_native = false;
+      if (p->d.engine == QI_ENGINE_NATIVE) {
+        set_error("native engine: this band table needs the two-pass kernels, which run 2^20 / 2^21-point transforms only");
+        rc = QI_ERR_UNSUPPORTED;
+      }
+    }
+  }
+  if (rc == QI_OK && !use_native) {
+    if (hipMalloc(&p->bank[bank], (size_t)B * L * esz) != hipSuccess) {
+      set_error("hipMalloc of the %zu-byte atom-spectrum bank failed", (size_t)B * L * esz);
+      rc = QI_ERR_NOMEM;
+    } else {
       rc = p->d.dtype == QI_F64 ? build_bank<double>(p, bank, B, d_par, st) : build_bank<float>(p, bank, B, d_par, st);
+    }
   }
   if (rc == QI_OK && hipStreamSynchronize(st) != hipSuccess) {
     set_error("bank build failed on the device: %s", hipGetErrorString(hipGetLastError()));

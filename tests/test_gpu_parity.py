@@ -7,6 +7,8 @@ Stated tolerances (max|delta| relative to max|reference| of the panel unless not
   float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-2 max, 1e-4 reductions
 Band tables, shift indices, STFT shapes / time / frequency axes: bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -435,6 +437,44 @@ def test_native_engines_other_band_tables(order, fs):
     ref.close()
 
 
+def test_native_split_bands_of_the_benchmark_table():
+    """The two lowest bands of the order-3 styx table at n = 2^20 have atoms longer than the record (the reference cuts
+    them off at |x| = n / 2, styx_cwt.py:113-144).  The native engine runs them as a tapered band on the zoom engine
+    plus edge items in the block launch, and nothing of the table is left for the two-pass kernels: every row against
+    the hipFFT engine (the reference's own algorithm), with and without a stored panel."""
+    from quantum_inferno_amd import _lib
+
+    n, fs, order = 1 << 20, 1000.0, 3
+    rng = np.random.default_rng(77)
+    # noise up to the record ends: the edge pieces weigh the samples half a record away from each output
+    x = (orc.synth_chirp(n, fs, 0, 1, np.float32) + 0.5 * rng.standard_normal(n).astype(np.float32))[None, :]
+    xt = torch.from_numpy(x).cuda()
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    ws = engine.TfrPlan.workspace_for(n, nb, np.float32, 1)
+    nat = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_NATIVE)
+    ref = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        plan.set_styx_bank(order, fs)
+    if "QI_NATIVE_SPLIT" not in os.environ and "QI_NATIVE_ZOOM" not in os.environ and "QI_NATIVE_BLOCK" not in os.environ:
+        assert nat.stage_bands("pass2")[0] == 0  # zoom + block engines produce all 48 bands
+        assert nat.stage_bands("zoom")[0] + nat.stage_bands("block")[0] == nb
+    a = nat.cwt(xt, coef=True, bits=True, reductions=True)
+    b = ref.cwt(xt, coef=True, bits=True, reductions=True)
+    for row in range(nb):  # per row: the two split bands are the weakest rows of the panel
+        scale = float(b.coef[0, row].abs().max())
+        assert float((a.coef[0, row] - b.coef[0, row]).abs().max()) <= 2e-5 * scale, row
+    big = b.coef.abs() >= 1e-2 * float(b.coef.abs().max())
+    assert float((a.bits - b.bits).abs()[big].max()) <= 1e-3
+    assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
+    assert torch.allclose(a.power_time, b.power_time, rtol=1e-3, atol=1e-6 * float(b.power_time.max()))
+    assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
+    r = nat.cwt(xt, coef=False, bits=False, reductions=True)  # reductions only: the split bands still meet in a scratch row
+    assert torch.equal(r.power_band, a.power_band) and torch.equal(r.power_time, a.power_time)
+    assert torch.equal(r.stats, a.stats)
+    nat.close()
+    ref.close()
+
+
 def test_fused_cwt_stx_call_matches_separate_calls():
     """qi_cwt_stx (both transforms of the same records in one call, the Stockwell bands formed from the even bins of
     the CWT's zero-padded spectrum) against qi_cwt followed by qi_stx: the CWT is the same computation (bit-equal),
@@ -460,26 +500,40 @@ def test_fused_cwt_stx_call_matches_separate_calls():
 
 
 @pytest.mark.parametrize("log2n", [18, 19, 21, 22])
-def test_native_stockwell_other_lengths(log2n):
-    """Stockwell transform at the other power-of-two lengths the native engine takes (its band tables need only the
-    zoom and block engines, which are not tied to the two-pass kernels' 2^20 / 2^21) against the hipFFT engine."""
+def test_native_engine_other_lengths(log2n):
+    """Stockwell transform and styx CWT at the other power-of-two lengths the native engine takes (their order-3 band
+    tables need only the zoom and block engines -- the CWT's longest atoms as split bands -- which are not tied to the
+    two-pass kernels' 2^20 / 2^21) against the hipFFT engine: every row, the fused reductions, and the fused call."""
     from quantum_inferno_amd import _lib
 
     n, fs, order = 1 << log2n, 1000.0, 3
-    x = torch.from_numpy(orc.synth_chirp(n, fs, 0, 1, np.float32)[None, :]).cuda()
+    rng = np.random.default_rng(log2n)
+    x = orc.synth_chirp(n, fs, 0, 1, np.float32) + 0.25 * rng.standard_normal(n).astype(np.float32)
+    x = torch.from_numpy(x[None, :]).cuda()
     nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
     ws = engine.TfrPlan.workspace_for(n, nb, np.float32, 1)
     nat = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_AUTO)
     ref = engine.TfrPlan(n, np.float32, None, ws, _lib.QI_ENGINE_HIPFFT)
     for plan in (nat, ref):
         plan.set_stx_bands(order, fs)
-    a = nat.stx(x, coef=True, reductions=True)
-    b = ref.stx(x, coef=True, reductions=True)
-    scale = float(b.coef.abs().max())
-    assert float((a.coef - b.coef).abs().amax(dim=2).max()) / scale <= 2e-5
-    assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
-    assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
-    assert nat.stage_bands("zoom")[2] + nat.stage_bands("block")[2] > 0  # the native engine did run
+        plan.set_styx_bank(order, fs)
+    knobs = any(k in os.environ for k in ("QI_NATIVE_ZOOM", "QI_NATIVE_BLOCK", "QI_NATIVE_SPLIT"))  # (they move bands to the two-pass kernels)
+    for which, name in ((2, "stx"), (0, "cwt")):
+        a = getattr(nat, name)(x, coef=True, reductions=True)
+        b = getattr(ref, name)(x, coef=True, reductions=True)
+        for row in range(nb):
+            scale = float(b.coef[0, row].abs().max())
+            assert float((a.coef[0, row] - b.coef[0, row]).abs().max()) <= 2e-5 * scale, (name, row)
+        assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
+        assert torch.allclose(a.power_time, b.power_time, rtol=1e-3, atol=1e-6 * float(b.power_time.max()))
+        assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
+        if not knobs:
+            assert nat.stage_bands("zoom")[which] + nat.stage_bands("block")[which] == nb  # the native engine did run
+        if name == "cwt":
+            fc, fs_ = nat.cwt_stx(x, coef=True, reductions=True)
+            assert torch.equal(fc.coef, a.coef)
+            assert float((fs_.coef - nat.stx(x, coef=True).coef).abs().max()) <= 2e-5 * float(fs_.coef.abs().max())
+        del a, b
     nat.close()
     ref.close()
 
