@@ -9,7 +9,7 @@ with more than one rank -- one RCCL gather of the reduced product to rank 0.
 Default workload = BASELINE.json configs[1]: 1 channel per GPU, 2^20 samples @ 1 kHz, order 3, fp32.
 A "point" is one complex TFR coefficient; points per step = 2 * channels * bands * n per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="after the warmup steps, keep stepping (untimed) until this much wall time has passed since "
+                         "their start: the GPU leaves its idle clocks only after ~0.1 s of load (0 = off)")
     ap.add_argument("--channels", type=int, default=1, help="records per GPU (weak scaling)")
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--order", type=float, default=3.0)
@@ -132,8 +135,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    # a step is a third of a millisecond: a few warmup steps end long before the clocks have left idle
+    settle_steps = 0
+    while True:
+        torch.cuda.synchronize()
+        done = (time.perf_counter() - t_warm) * 1e3 >= args.settle_ms
+        if world > 1:  # every rank runs the same number of steps (each step ends in a collective)
+            flag = torch.tensor([1.0 if done else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(flag.item() > 0.5)
+        if done:
+            break
+        for _ in range(10):
+            step()
+        settle_steps += 10
     # untimed: every stage timed with HIP events, to find the dominant stage and report the breakdown
     plan.profile(True)
     for _ in range(3):
@@ -189,6 +207,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": settle_steps,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",

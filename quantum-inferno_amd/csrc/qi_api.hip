@@ -314,6 +314,8 @@ struct qi_plan {
   std::vector<int32_t> h_split_bands;
   int32_t nsplit = 0;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
+  int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
+  int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
@@ -894,7 +896,10 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
     // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30
     const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
-    if (can_block && block_group_of(w) > 0) {
+    // (a band of the widest reach groups -- half of each 4096-sample block is overlap there -- goes to the zoom
+    // engine instead when its spectrum fits one of its grids)
+    if (can_block && block_group_of(w) > 0 &&
+        !(block_group_of(w) > p->native_blk_maxwq && zoom_class(p, bank, L, len) >= 0)) {
       BlockPick pk{j, block_group_of(w), 0};
       const double p_re = h_par[j], p_im = h_par[B + j], om = h_par[2 * B + j], am = h_par[3 * B + j];
       // a pure Gabor atom at least 2.75 samples wide (no alias of its Gaussian spectrum above 1e-16) with its centre
@@ -1411,10 +1416,17 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(native::launch_edge<T>(e, ct, want_time ? edge_time : nullptr, want_band ? part_band : nullptr, nbk,
                                     nbk - 1, want_stat ? part_stat : nullptr, stat_slots - p->nedge, st));
     }
-    if (time_via_part)
+    if (time_via_part && (want_band || want_stat) && p->native_tail)
+      QI_TRY(native::launch_tail<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
+                                    shorts ? edge_time : nullptr, p->edge_wmax, want_band ? part_band : nullptr,
+                                    want_stat ? part_stat : nullptr,
+                                    want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
+                                    want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, B, nbk, stat_slots,
+                                    shorts ? nullptr : p->d_band_slots[kind], st));
+    else if (time_via_part)
       QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
                                            shorts ? edge_time : nullptr, p->edge_wmax, st));
-    if (want_band || want_stat)
+    if ((want_band || want_stat) && !(time_via_part && p->native_tail))
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nbk, stat_slots,
@@ -1596,6 +1608,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
+  if (const char* e = getenv("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
@@ -1819,7 +1833,10 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       // the band's time-domain kernel is a Gaussian of standard deviation sigma_j samples (above 2^-30 of its peak
       // within sqrt(60 ln 2) sigma); it is only that short if the frequency window has decayed before Nyquist
       const double reach = std::ceil(std::sqrt(60.0 * M_LN2) * sigma[j]) + 1.0;
-      if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0) {
+      const double kh0 = std::floor(std::sqrt(30.0) / coef[j]);
+      const bool zoom_first = block_group_of(reach) > p->native_blk_maxwq && 2 * kh0 + 1 < (double)p->n &&
+                              zoom_class(p, 2, p->n, (int64_t)(2 * kh0 + 1)) >= 0;
+      if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 && !zoom_first) {
         BlockPick pk{j, block_group_of(reach), shift_index[j]};
         // the band's filter spectrum is the Gaussian window itself, centred on the band's shift index
         pk.analytic = 1;

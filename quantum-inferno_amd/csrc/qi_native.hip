@@ -16,6 +16,7 @@
 #include "qi_device.hpp"
 #include "qi_native.hpp"
 #include "qi_fft_reg.hpp"
+#include "qi_finalize.hpp"
 
 namespace qi {
 namespace native {
@@ -573,15 +574,16 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   }
 }
 
-// power_time[c][t] = sum over chunks of time_part[c][q][t] (+ the corrected edge samples of the short-atom bands)
+// power_time[c][t] = sum over chunks of time_part[c][q][t] (+ the corrected edge samples of the short-atom bands);
+// workgroup bx of gx
 template <typename T, int VEC>  // VEC samples per thread and plane (4: one 16-byte float load; needs aligned rows)
-__global__ void __launch_bounds__(256) k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
-                                                     const T* __restrict__ edge_time, int64_t wmax) {
+__device__ __forceinline__ void time_reduce_block(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
+                                                  const T* __restrict__ edge_time, int64_t wmax, int64_t bx, int64_t gx,
+                                                  int64_t c) {
   struct alignas(sizeof(T) * VEC) Pack {
     T v[VEC];
   };
-  const int64_t c = blockIdx.y;
-  for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; t < n; t += (int64_t)gridDim.x * blockDim.x * VEC) {
+  for (int64_t t = (bx * blockDim.x + threadIdx.x) * VEC; t < n; t += gx * blockDim.x * VEC) {
     if (t + VEC <= n) {
       Pack s = *reinterpret_cast<const Pack*>(part + (c * nchunk) * n + t);
       for (int q = 1; q < nchunk; ++q) {
@@ -609,6 +611,34 @@ __global__ void __launch_bounds__(256) k_time_reduce(const T* __restrict__ part,
       }
     }
   }
+}
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_time_reduce(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
+                                                     const T* __restrict__ edge_time, int64_t wmax) {
+  time_reduce_block<T, VEC>(part, out, n, nchunk, edge_time, wmax, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// The tail of a transform in one launch: the first nfin workgroups of a record finalise the per-band and whole-panel
+// reductions (finalize_block), the others sum the per-time planes.
+struct TailFin {
+  const double* part_band;
+  const double* part_stat;
+  double* power_band;
+  double* stats;
+  int64_t B, nblk, nstat;
+  const int32_t* band_slots;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_tail(const T* __restrict__ part, T* __restrict__ out, int64_t n, int nchunk,
+                                              const T* __restrict__ edge_time, int64_t wmax, TailFin f, int nfin) {
+  __shared__ double s[3][256 / kWave];
+  if ((int)blockIdx.x < nfin) {
+    finalize_block(f.part_band, f.part_stat, f.power_band, f.stats, f.B, f.nblk, f.nstat, f.band_slots, blockIdx.x,
+                   blockIdx.y, s);
+    return;
+  }
+  time_reduce_block<T, VEC>(part, out, n, nchunk, edge_time, wmax, (int64_t)blockIdx.x - nfin, (int64_t)gridDim.x - nfin,
+                            blockIdx.y);
 }
 
 // Xn[c][k] = X2n[c][2k]: the n-point spectrum of a record is the even bins of its zero-padded 2n-point spectrum
@@ -947,6 +977,26 @@ int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, 
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
+template <typename T>
+int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
+                const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t B,
+                int64_t nblk, int64_t nstat, const int32_t* band_slots, hipStream_t st) {
+  const bool aligned = n % 4 == 0 && reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0 &&
+                       reinterpret_cast<uintptr_t>(part) % (4 * sizeof(T)) == 0;
+  if (!aligned) {  // (cannot happen for the engine's power-of-two records: two launches)
+    if (int rc = launch_time_reduce<T>(part, out, C, n, nchunk, edge_time, wmax, st)) return rc;
+    return launch_finalize(part_band, part_stat, power_band, stats, C, B, nblk, nstat, st, band_slots);
+  }
+  const TailFin f{part_band, part_stat, power_band, stats, B, nblk, nstat, band_slots};
+  const int nfin = (int)B + 1;
+  const int64_t gt = ceil_div(n, 1024) > 4096 ? 4096 : ceil_div(n, 1024);
+  dim3 g((unsigned)(gt + nfin), (unsigned)C);
+  k_tail<T, 4><<<g, 256, 0, st>>>(part, out, n, nchunk, edge_time, wmax, f, nfin);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_tail<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, const double*,
+                                const double*, double*, double*, int64_t, int64_t, int64_t, const int32_t*, hipStream_t);
 template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, hipStream_t);
 template int launch_time_reduce<double>(const double*, double*, int64_t, int64_t, int, const double*, int64_t,
                                         hipStream_t);

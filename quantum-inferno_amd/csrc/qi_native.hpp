@@ -204,6 +204,11 @@ void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                        hipStream_t st);
+// time reduction + finalisation of the reductions in one launch (both requested)
+template <typename T>
+int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
+                const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t B,
+                int64_t nblk, int64_t nstat, const int32_t* band_slots, hipStream_t st);
 template <typename T>
 int launch_even_bins(const cplx<T>* x2, cplx<T>* x1, int64_t C, int64_t n, hipStream_t st);
 template <typename T>
