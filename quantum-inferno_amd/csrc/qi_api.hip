@@ -314,6 +314,7 @@ struct qi_plan {
   std::vector<int32_t> h_split_bands;
   int32_t nsplit = 0;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
+  int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
@@ -695,6 +696,17 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       b.kappa_frac = (float)(picks[r].kappa - std::floor(picks[r].kappa));
       b.cw = (float)picks[r].cw;
       b.amp = (float)picks[r].amp;
+      // weights >= 2^-30 of the peak: |cw dk| <= sqrt(30)
+      const double half = std::ceil(std::sqrt(30.0) / picks[r].cw);
+      if (b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
+        b.narrow = 1;
+        b.klo = (int32_t)((((int64_t)std::llround(picks[r].kappa) - 128) % native::kBlk + native::kBlk) % native::kBlk);
+        const int ba = b.klo >> 8;
+        b.rot_a[0] = (float)std::cos(2.0 * M_PI * ba / 16.0);
+        b.rot_a[1] = (float)std::sin(2.0 * M_PI * ba / 16.0);
+        b.rot_b[0] = (float)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+        b.rot_b[1] = (float)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+      }
       for (int k = 0; k < 4; ++k) {
         // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
         const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
@@ -711,9 +723,10 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
     if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
     if (getenv("QI_NATIVE_VERBOSE"))
-      fprintf(stderr, "[qi plan] block table %d, reach <= %d: %d bands (%d analytic) in %d workgroups x %lld blocks\n", kind,
+      fprintf(stderr, "[qi plan] block table %d, reach <= %d: %d bands (%d analytic, %d narrow) in %d workgroups x %lld blocks\n", kind,
               256 * wqs[g], count,
               (int)std::count_if(list.begin() + first, list.end(), [](const native::BlockBand& b) { return b.analytic != 0; }),
+              (int)std::count_if(list.begin() + first, list.end(), [](const native::BlockBand& b) { return b.narrow != 0; }),
               nchunk, (long long)nblocks);
     for (int32_t q = first; q < (int32_t)list.size(); ++q) bt.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
     for (int32_t c = 0; c < nchunk; ++c) {
@@ -1608,6 +1621,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
+  if (const char* e = getenv("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
   if (const char* e = getenv("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;

@@ -96,6 +96,9 @@ __device__ __forceinline__ void mul_powers16(cplx<T> (&v)[16], cplx<T> w) {
 // holds two adjacent outputs and stores them as 16 bytes (the epilogue is store-issue bound: half the store
 // instructions).  `w` = W4096^col.
 template <typename T, int DIR>
+__device__ __forceinline__ void fft4096_tail(cplx<T> (&v)[16], cplx<T>* __restrict__ buf,
+                                             const cplx<T>* __restrict__ tw256, int tid, int col);
+template <typename T, int DIR>
 __device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
                                         cplx<T> w, int tid, int col) {
   fft_reg<T, 16, DIR>(v);  // over k2 -> q2
@@ -103,6 +106,61 @@ __device__ __forceinline__ void fft4096(cplx<T> (&v)[16], cplx<T>* __restrict__ 
   // in registers across the band loop
   asm volatile("" : "+v"(w.x), "+v"(w.y));
   mul_powers16<T>(v, DIR > 0 ? w : cconj<T>(w));
+  fft4096_tail<T, DIR>(v, buf, tw256, tid, col);
+}
+
+// A spectrum with at most ONE non-zero value y among a thread's sixteen (bin k = col + 256 b0): the first pass of the
+// inverse transform and its twiddles collapse to v[brev(q)] = y om^q, om = exp(2 pi i k / 4096) (binary products,
+// depth <= 4 roundings like mul_powers16).
+template <typename T>
+__device__ __forceinline__ void sparse_head16(cplx<T> (&v)[16], cplx<T> y, cplx<T> om) {
+  const cplx<T> u1 = om, u2 = cmul(u1, u1), u4 = cmul(u2, u2), u8 = cmul(u4, u4);
+  v[brev(0, 4)] = y;
+  v[brev(1, 4)] = cmul(y, u1);
+  v[brev(2, 4)] = cmul(y, u2);
+  v[brev(3, 4)] = cmul(v[brev(2, 4)], u1);
+  v[brev(4, 4)] = cmul(y, u4);
+  v[brev(5, 4)] = cmul(v[brev(4, 4)], u1);
+  v[brev(6, 4)] = cmul(v[brev(4, 4)], u2);
+  v[brev(7, 4)] = cmul(v[brev(6, 4)], u1);
+  v[brev(8, 4)] = cmul(y, u8);
+  v[brev(9, 4)] = cmul(v[brev(8, 4)], u1);
+  v[brev(10, 4)] = cmul(v[brev(8, 4)], u2);
+  v[brev(11, 4)] = cmul(v[brev(10, 4)], u1);
+  v[brev(12, 4)] = cmul(v[brev(8, 4)], u4);
+  v[brev(13, 4)] = cmul(v[brev(12, 4)], u1);
+  v[brev(14, 4)] = cmul(v[brev(12, 4)], u2);
+  v[brev(15, 4)] = cmul(v[brev(14, 4)], u1);
+}
+
+// the value of a thread's sixteen that index b0 selects, b0 in {ba, ba + 1 mod 16} with ba the same for the workgroup
+// (a switch over constant indices: a computed index would move the sixteen values to scratch memory)
+template <typename T>
+__device__ __forceinline__ cplx<T> pick_pair16(const cplx<T> (&S)[16], int ba, bool first) {
+  cplx<T> xa, xb;
+#define QI_PICK(B)                                                                \
+  case B:                                                                         \
+    xa = S[B];                                                                    \
+    xb = S[(B + 1) & 15];                                                         \
+    asm volatile("" : "+v"(xa.x), "+v"(xa.y), "+v"(xb.x), "+v"(xb.y)); /* keeps the cases apart (no index table) */ \
+    break;
+  switch (ba) {
+    QI_PICK(0) QI_PICK(1) QI_PICK(2) QI_PICK(3) QI_PICK(4) QI_PICK(5) QI_PICK(6) QI_PICK(7)
+    QI_PICK(8) QI_PICK(9) QI_PICK(10) QI_PICK(11) QI_PICK(12) QI_PICK(13) QI_PICK(14)
+    default:
+      xa = S[15];
+      xb = S[0];
+      asm volatile("" : "+v"(xa.x), "+v"(xa.y), "+v"(xb.x), "+v"(xb.y));
+      break;
+  }
+#undef QI_PICK
+  return first ? xa : xb;
+}
+
+// everything after the first radix-16 pass and its twiddles: two exchanges through LDS, two register passes
+template <typename T, int DIR>
+__device__ __forceinline__ void fft4096_tail(cplx<T> (&v)[16], cplx<T>* __restrict__ buf,
+                                             const cplx<T>* __restrict__ tw256, int tid, int col) {
   __syncthreads();  // the previous transform's readers are done with buf
   {
     cplx<T> t[16];
@@ -197,7 +255,30 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
     const BlockBand bd = bd_next;
     if (jj + 1 < it.band_count) bd_next = a.bands[it.band_first + jj + 1];
     cplx<T> v[16];
-    if (bd.analytic) {
+    if (bd.narrow) {
+      // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
+      // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
+      QI_BSTAMP(1);
+      QI_BSTAMP(2);
+      const int kres = (col - bd.klo) & 255;
+      const int k = (bd.klo + kres) & (kBlk - 1);
+      const bool first = (k >> 8) == (bd.klo >> 8);
+      const cplx<T> x = pick_pair16<T>(S, __builtin_amdgcn_readfirstlane(bd.klo >> 8), first);
+      T dk = (T)(k - bd.kappa_int) - (T)bd.kappa_frac;
+      T amp = (T)bd.amp;
+      if (dk > (T)(kBlk / 2)) {
+        dk -= (T)kBlk;
+        if (!DEMOD) amp = -amp;  // half-integer sample grid: the aliases alternate in sign
+      }
+      if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
+      const T e = (T)bd.cw * dk;
+      const T r = amp * fast_exp2(-e * e);
+      cplx<T> wq = w;
+      asm volatile("" : "+v"(wq.x), "+v"(wq.y));
+      const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
+      sparse_head16<T>(v, mk<T>(x.x * r, x.y * r), om);
+      if (!QI_BDBG(4)) fft4096_tail<T, 1>(v, buf, tw256, tid, col);
+    } else if (bd.analytic) {
       // Gaussian filter spectrum in registers: no table traffic (the table rows cost as much L2 bandwidth as the
       // panel costs HBM bandwidth)
       QI_BSTAMP(1);
@@ -228,7 +309,7 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    if (!QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    if (!bd.narrow && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
     QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;

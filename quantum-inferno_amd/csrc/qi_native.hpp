@@ -95,6 +95,11 @@ struct BlockBand {
   // analytic filter: weight(k) = amp * exp2(-(cw * dk)^2), dk = k - (kappa_int + kappa_frac) wrapped to +-kBlk / 2
   int32_t kappa_int;
   float kappa_frac, cw, amp;
+  // narrow = 1: the weights above 2^-30 of the peak lie within the 256 bins from `klo` (mod kBlk), so a thread holds at
+  // most one non-zero value of the filtered spectrum and the first radix-16 pass of the inverse transform is a
+  // product with powers of one phasor; rot_a / rot_b = exp(2 pi i b / 16) for b = klo / 256 and the next one
+  int32_t narrow, klo;
+  float rot_a[2], rot_b[2];
 };
 struct BlockItem {  // one workgroup of the block launch
   int32_t wq;          // reach group: taps within 256 * wq samples; negative: the edge pieces (reach group -wq) of
