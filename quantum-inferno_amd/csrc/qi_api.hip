@@ -226,6 +226,29 @@ static std::map<int, FftCache> g_stft_fft;  // per device
 
 using namespace qi;
 
+// qi_cwt_stx: the CWT run leaves its block launch and its tail to the Stockwell run, which issues them together with
+// its own (one launch each: the two block launches share the forward transform of every block)
+struct TailCall {  // the arguments of one native::launch_tail
+  const float* time_part = nullptr;
+  float* out_time = nullptr;
+  int64_t ct = 0, n = 0;
+  int chunk_total = 0;
+  const double* part_band = nullptr;
+  const double* part_stat = nullptr;
+  double* power_band = nullptr;
+  double* stats = nullptr;
+  int64_t B = 0, nbk = 0, stat_slots = 0;
+  const int32_t* band_slots = nullptr;
+};
+struct FusedCarry {
+  bool active = false;
+  size_t ws_used = 0;  // bytes of the workspace the CWT run's scratch occupies (kept until its deferred launches ran)
+  native::BlockArgs<float> blk{};
+  int demod = 0;
+  int64_t ct = 0;
+  TailCall tail;
+};
+
 struct qi_plan {
   qi_plan_desc d{};
   int64_t n = 0;
@@ -283,6 +306,7 @@ struct qi_plan {
     int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
     int64_t max_blocks = 0;  // partial slots a band row needs
     std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
+    std::vector<native::BlockItem> h_items;             // host copy of d_items (the joint launch list is made from it)
     void release() {
       if (bank) (void)hipFree(bank);
       if (d_bands) (void)hipFree(d_bands);
@@ -314,6 +338,11 @@ struct qi_plan {
   std::vector<int32_t> h_split_bands;
   int32_t nsplit = 0;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
+  FusedCarry carry;
+  native::DualItem* d_dual = nullptr;  // joint block launch of qi_cwt_stx (styx + Stockwell tables), built on first use
+  int32_t n_dual = 0;
+  bool dual_valid = false;
+  int native_fuse = 2;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one launch each
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
@@ -670,6 +699,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
                        hipStream_t st) {
   auto& bt = p->blk[kind];
   bt.release();
+  p->dual_valid = false;
   if (picks.empty()) return QI_OK;
   const int32_t rows = (int32_t)picks.size();
   QI_TRY(fft_c2c<double>(p->fft, taps, native::kBlk, rows, HIPFFT_FORWARD, st));
@@ -765,6 +795,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   }
   QI_HIP(hipMalloc((void**)&bt.d_bands, list.size() * sizeof(native::BlockBand)));
   QI_HIP(hipMemcpy(bt.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
+  bt.h_items = items;
   QI_HIP(hipMalloc((void**)&bt.d_items, items.size() * sizeof(native::BlockItem)));
   QI_HIP(hipMemcpy(bt.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
   QI_HIP(hipStreamSynchronize(st));
@@ -1047,9 +1078,75 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
 // the 2n-point linear part and the n-point circular part for short atoms) pass 1 for the wide bands and pass 2 with
 // the fused epilogue for every band, the edge correction of the short-atom bands, and a fixed-order finalisation of
 // the reductions.
+// Work items of the joint block launch: the items of the styx table (0) and of the Stockwell table (2) on the same
+// (reach group, block) are paired chunk by chunk -- one forward transform serves both; what has no partner stays single;
+// the edge items of the styx table keep their place at the end.
+int build_dual_items(qi_plan* p) {
+  if (p->dual_valid) return QI_OK;
+  if (p->d_dual) (void)hipFree(p->d_dual);
+  p->d_dual = nullptr;
+  p->n_dual = 0;
+  std::map<std::pair<int32_t, int32_t>, std::pair<std::vector<native::BlockItem>, std::vector<native::BlockItem>>> at;
+  std::vector<native::DualItem> dual, edge;
+  for (const auto& it : p->blk[0].h_items) {
+    if (it.wq < 0) edge.push_back({it.wq, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, 0, 0, 0, 0});
+    else at[{it.wq, it.block}].first.push_back(it);
+  }
+  for (const auto& it : p->blk[2].h_items) at[{it.wq, it.block}].second.push_back(it);
+  for (const auto& kv : at) {
+    const auto& a = kv.second.first;
+    const auto& b = kv.second.second;
+    for (size_t i = 0; i < std::max(a.size(), b.size()); ++i) {
+      native::DualItem d{kv.first.first, kv.first.second, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < a.size()) {
+        d.first0 = a[i].band_first;
+        d.count0 = a[i].band_count;
+        d.plane0 = a[i].plane;
+        d.slot0 = a[i].stat_slot;
+      }
+      if (i < b.size()) {
+        d.first2 = b[i].band_first;
+        d.count2 = b[i].band_count;
+        d.plane2 = b[i].plane;
+        d.slot2 = b[i].stat_slot;
+      }
+      dual.push_back(d);
+    }
+  }
+  std::stable_sort(dual.begin(), dual.end(), [](const native::DualItem& x, const native::DualItem& y) {
+    return x.count0 + x.count2 > y.count0 + y.count2;
+  });
+  dual.insert(dual.end(), edge.begin(), edge.end());
+  if (dual.empty()) return QI_OK;
+  QI_HIP(hipMalloc((void**)&p->d_dual, dual.size() * sizeof(native::DualItem)));
+  QI_HIP(hipMemcpy(p->d_dual, dual.data(), dual.size() * sizeof(native::DualItem), hipMemcpyHostToDevice));
+  p->n_dual = (int32_t)dual.size();
+  p->dual_valid = true;
+  return QI_OK;
+}
+
+int launch_tail_call(const TailCall& t, hipStream_t st) {
+  return native::launch_tail<float>(t.time_part, t.out_time, t.ct, t.n, t.chunk_total, nullptr, 0, t.part_band, t.part_stat,
+                                    t.power_band, t.stats, t.B, t.nbk, t.stat_slots, t.band_slots, st);
+}
+
+// the deferred launches of a CWT run, on their own
+int flush_carry(qi_plan* p, FusedCarry* c, hipStream_t st) {
+  if (!c || !c->active) return QI_OK;
+  c->active = false;
+  p->prof.begin(st, QI_STAGE_BLOCK);
+  QI_TRY(native::launch_block<float>(c->blk, c->demod, c->ct, st));
+  p->prof.end(QI_STAGE_BLOCK, st);
+  p->prof.begin(st, QI_STAGE_EPILOGUE);
+  QI_TRY(launch_tail_call(c->tail, st));
+  p->prof.end(QI_STAGE_EPILOGUE, st);
+  return QI_OK;
+}
+
 template <typename T>
 int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st,
-               bool may_share = false) {
+               bool may_share = false, FusedCarry* defer = nullptr, FusedCarry* finish = nullptr) {
+  static_assert(std::is_same<T, float>::value, "the native engine is float32");
   struct Sub {
     const qi_plan::NativeTable* t;
     int kernel_kind;
@@ -1205,6 +1302,17 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     set_error("internal: shared spectra need all records in one tile");  // cannot happen: the CWT scratch is larger
     return QI_ERR_STATE;
   }
+  const bool tail_one = time_via_part && (want_band || want_stat) && p->native_tail;
+  const bool overlap = blocks && p->native_overlap && nsplit == 0;  // (edge items need the zoom launch's output)
+  // qi_cwt_stx: a CWT run whose records fit one tile leaves its block launch and tail to the Stockwell run ...
+  const bool deferring = defer && kind == 0 && Ct == C && blocks && !overlap && !shorts && tail_one;
+  // ... which keeps the CWT run's scratch intact (its own follows it; only the spectra are shared) and finishes both
+  bool finishing = finish && finish->active && kind == 2 && share && blocks && !overlap && tail_one;
+  if (finishing) {
+    const size_t need = align_up(e_x * (size_t)C) + align_up(finish->ws_used) + (per_chan - e_x) * (size_t)C + 64 * 256;
+    if (need > p->ws_bytes) finishing = false;
+  }
+  if (finish && finish->active && !finishing) QI_TRY(flush_carry(p, finish, st));  // before this run reuses the scratch
   if (kind == 0) {  // what this call will leave behind for a following qi_cwt_stx Stockwell call
     p->shared_valid = Ct == C;
     p->shared_sig = sig_v;
@@ -1219,6 +1327,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     return r;
   };
   cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
+  if (finishing) w = p->ws + align_up(finish->ws_used);
   cplx<T>* Xn = reinterpret_cast<cplx<T>*>(carve(e_xn));
   cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
   char* parts0 = w;
@@ -1232,7 +1341,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   cplx<T>* zcoarse = e_zc ? reinterpret_cast<cplx<T>*>(carve(e_zc)) : nullptr;
   cplx<T>* zadd = e_add ? reinterpret_cast<cplx<T>*>(carve(e_add)) : nullptr;
 
-  const bool overlap = blocks && p->native_overlap && nsplit == 0;  // (edge items need the zoom launch's output)
   if (overlap && !p->side) {
     QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
     QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -1269,9 +1377,23 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.two_over_n = (float)(2.0 / (double)n);
       b.debug = p->native_debug;
       b.stamps = p->blk_stamps;
+      if (deferring) {  // the Stockwell run of qi_cwt_stx launches it
+        defer->blk = b;
+        defer->demod = bt.demod;
+        defer->ct = ct;
+        return QI_OK;
+      }
       p->prof.unchain_span();
       p->prof.begin(bs, QI_STAGE_BLOCK);
-      QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
+      const bool joint = finishing && p->native_fuse > 1 && finish->ct == ct && !finish->demod && bt.demod &&
+                         (finish->blk.coef != nullptr) == (b.coef != nullptr) && (finish->blk.bits != nullptr) == (b.bits != nullptr);
+      if (joint) {
+        QI_TRY(build_dual_items(p));
+        QI_TRY(native::launch_block_dual<T>(finish->blk, b, p->d_dual, p->n_dual, ct, bs));
+      } else {
+        if (finishing) QI_TRY(native::launch_block<T>(finish->blk, finish->demod, finish->ct, bs));
+        QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
+      }
       p->prof.end(QI_STAGE_BLOCK, bs);
       p->prof.unchain_span();
       return QI_OK;
@@ -1429,7 +1551,40 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(native::launch_edge<T>(e, ct, want_time ? edge_time : nullptr, want_band ? part_band : nullptr, nbk,
                                     nbk - 1, want_stat ? part_stat : nullptr, stat_slots - p->nedge, st));
     }
-    if (time_via_part && (want_band || want_stat) && p->native_tail)
+    if (deferring || finishing) {
+      TailCall tc;
+      tc.time_part = time_part;
+      tc.out_time = static_cast<T*>(out->power_time) + c0 * n;
+      tc.ct = ct;
+      tc.n = n;
+      tc.chunk_total = chunk_total;
+      tc.part_band = want_band ? part_band : nullptr;
+      tc.part_stat = want_stat ? part_stat : nullptr;
+      tc.power_band = want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr;
+      tc.stats = want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr;
+      tc.B = B;
+      tc.nbk = nbk;
+      tc.stat_slots = stat_slots;
+      tc.band_slots = p->d_band_slots[kind];
+      if (deferring) {
+        defer->tail = tc;
+        defer->ws_used = (size_t)(w - p->ws);
+        defer->active = true;
+      } else {
+        finish->active = false;
+        const TailCall& t0 = finish->tail;
+        if (t0.ct == tc.ct && t0.n == tc.n) {
+          QI_TRY(native::launch_tail2<float>(t0.time_part, t0.out_time, t0.chunk_total, t0.part_band, t0.part_stat,
+                                             t0.power_band, t0.stats, t0.B, t0.nbk, t0.stat_slots, t0.band_slots,
+                                             tc.time_part, tc.out_time, tc.chunk_total, tc.part_band, tc.part_stat,
+                                             tc.power_band, tc.stats, tc.B, tc.nbk, tc.stat_slots, tc.band_slots, tc.ct,
+                                             tc.n, st));
+        } else {
+          QI_TRY(launch_tail_call(t0, st));
+          QI_TRY(launch_tail_call(tc, st));
+        }
+      }
+    } else if (tail_one)
       QI_TRY(native::launch_tail<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
                                     shorts ? edge_time : nullptr, p->edge_wmax, want_band ? part_band : nullptr,
                                     want_stat ? part_stat : nullptr,
@@ -1439,7 +1594,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     else if (time_via_part)
       QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
                                            shorts ? edge_time : nullptr, p->edge_wmax, st));
-    if ((want_band || want_stat) && !(time_via_part && p->native_tail))
+    if ((want_band || want_stat) && !tail_one)
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nbk, stat_slots,
@@ -1621,6 +1776,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
+  if (const char* e = getenv("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
   if (const char* e = getenv("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
@@ -1696,6 +1852,7 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->d_edge) (void)hipFree(p->d_edge);
   if (p->split_bank) (void)hipFree(p->split_bank);
   if (p->d_split_bands) (void)hipFree(p->d_split_bands);
+  if (p->d_dual) (void)hipFree(p->d_dual);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);
@@ -1959,11 +2116,25 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
                qi_stream stream) {
   QI_REQUIRE(p && sig && out_cwt && out_stx, "null argument");
   QI_REQUIRE(bank == QI_BANK_STYX, "qi_cwt_stx runs the styx bank (bank %d given)", bank);
-  QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
+  const bool fuse = p->native_fuse && p->nat[bank].ready && p->nat[2].ready;
+  p->carry.active = false;
+  QI_REQUIRE(C > 0, "n_channels must be positive");
+  if (fuse) {
+    DeviceGuard g0(p->d.device);
+    p->prof.unchain();
+    QI_TRY(run_native<float>(p, bank, sig, C, out_cwt, (hipStream_t)stream, false, &p->carry, nullptr));
+  } else {
+    QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
+  }
   DeviceGuard g(p->d.device);
   p->prof.unchain();
   if (p->nat[2].ready) {
-    const int rc = run_native<float>(p, 2, sig, C, out_stx, (hipStream_t)stream, /*may_share=*/p->nat[bank].ready);
+    int rc = run_native<float>(p, 2, sig, C, out_stx, (hipStream_t)stream, /*may_share=*/p->nat[bank].ready, nullptr,
+                               &p->carry);
+    if (p->carry.active) {  // the Stockwell run failed before it reached the deferred launches
+      const int rc2 = flush_carry(p, &p->carry, (hipStream_t)stream);
+      if (rc == QI_OK) rc = rc2;
+    }
     p->shared_valid = false;
     return rc;
   }

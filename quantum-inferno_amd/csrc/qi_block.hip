@@ -189,17 +189,43 @@ __device__ __forceinline__ void fft4096_tail(cplx<T> (&v)[16], cplx<T>* __restri
   fft_reg<T, 16, DIR>(v);  // over k0 -> q0
 }
 
-// One work item: block `it.block` of the reach group WQ (taps within W = 256 WQ samples), bands
-// [it.band_first, it.band_first + it.band_count) of the launch's list.  DEMOD: Stockwell (circular loads, demodulated
-// outputs).
+// Spectrum of record samples [t0, t0 + 4096) (CIRC: the record wraps -- Stockwell; else it is zero outside -- the
+// reference's zero padding), in natural order: S[c] = bin col + 256 c.
+template <typename T, bool CIRC>
+__device__ __forceinline__ void block_forward(const T* __restrict__ sig, int64_t n, int64_t t0, cplx<T> (&S)[16],
+                                              cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256, cplx<T> w,
+                                              int tid, int col) {
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    int64_t t = t0 + col + 256 * b;
+    T x;
+    if (CIRC) {
+      t = (t + n) & (n - 1);  // circular (n is a power of two, t >= -n)
+      x = sig[t];
+    } else {
+      x = (t >= 0 && t < n) ? sig[t] : T(0);
+    }
+    S[b] = mk<T>(x, T(0));
+  }
+  fft4096<T, -1>(S, buf, tw256, w, tid, col);
+  cplx<T> t[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) S[c] = t[c];
+}
+
+// The bands [band_first, band_first + band_count) of the launch's list on block `blk` of reach group WQ, from the
+// block's spectrum S (natural order; rotated in place here for the Gabor banks).  DEMOD: Stockwell (demodulated outputs).
 template <typename T, int WQ, bool DEMOD, bool COEF, bool BITS>
-__device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
-                                           const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
-                                           cplx<T> w) {
+__device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i, int32_t band_first, int32_t band_count,
+                                            int32_t plane, int32_t stat_slot, cplx<T> (&S)[16], cplx<T>* __restrict__ buf,
+                                            const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
+                                            cplx<T> w) {
   constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // the column this thread owns
-  const int64_t blk = it.block, ch = blockIdx.z;
+  const int64_t blk = blk_i, ch = blockIdx.z;
   const int64_t n = a.n;
 #ifdef QI_NATIVE_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -207,35 +233,13 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
 #endif
   // record samples [t0, t0 + 4096), outputs [t0 + W, t0 + W + V)
   const int64_t t0 = blk * V - W;
-  cplx<T> S[16];
-  {
-    const T* __restrict__ sig = a.sig + ch * n;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      int64_t t = t0 + col + 256 * b;
-      T x;
-      if (DEMOD) {
-        t = (t + n) & (n - 1);  // circular (n is a power of two, t >= -n)
-        x = sig[t];
-      } else {
-        x = (t >= 0 && t < n) ? sig[t] : T(0);
-      }
-      S[b] = mk<T>(x, T(0));
-    }
-    fft4096<T, -1>(S, buf, tw256, w, tid, col);
-    cplx<T> t[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) S[c] = t[c];
-    if (!DEMOD) {
-      // Gabor banks: the half-sample offset of the atoms (styx_cwt.py:113-144) is the factor exp(-i theta_k / 2) of
-      // every filter spectrum; it goes into the block spectrum once, which leaves REAL Gaussian weights per band
-      float sn, cs;
-      sincospif(-(float)col * (1.0f / (float)kBlk), &sn, &cs);
-      const cplx<T> r0 = mk<T>((T)cs, (T)sn);
-      rotate_rows16<T>(S, r0, std::make_integer_sequence<int, 16>{});
-    }
+  if (!DEMOD) {
+    // Gabor banks: the half-sample offset of the atoms (styx_cwt.py:113-144) is the factor exp(-i theta_k / 2) of
+    // every filter spectrum; it goes into the block spectrum once, which leaves REAL Gaussian weights per band
+    float sn, cs;
+    sincospif(-(float)col * (1.0f / (float)kBlk), &sn, &cs);
+    const cplx<T> r0 = mk<T>((T)cs, (T)sn);
+    rotate_rows16<T>(S, r0, std::make_integer_sequence<int, 16>{});
   }
 
   QI_BSTAMP(0);
@@ -250,10 +254,10 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
   int pending = -1, par = 0;  // band whose wave sums sit in s_red[par ^ 1] until a barrier has passed
 
   // the band descriptor is fetched one band ahead: its load would otherwise sit in front of the filter loads
-  BlockBand bd_next = a.bands[it.band_first];
-  for (int jj = 0; jj < it.band_count; ++jj) {
+  BlockBand bd_next = a.bands[band_first];
+  for (int jj = 0; jj < band_count; ++jj) {
     const BlockBand bd = bd_next;
-    if (jj + 1 < it.band_count) bd_next = a.bands[it.band_first + jj + 1];
+    if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
     cplx<T> v[16];
     if (bd.narrow) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
@@ -387,13 +391,13 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
   if (a.stamps && tid == 0) {
     unsigned long long* o = a.stamps + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
     for (int k = 0; k < 5; ++k) o[k] = st_acc[k];
-    o[5] = (unsigned long long)it.band_count;
+    o[5] = (unsigned long long)band_count;
   }
 #endif
 
   T tot = T(0);
   char* __restrict__ time_row = reinterpret_cast<char*>(
-      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + it.plane) * n : nullptr);
+      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + plane) * n : nullptr);
 #pragma unroll
   for (int i = 0; i < NOUT; i += 2) {
     tot += col_p[i] + col_p[i + 1];
@@ -424,11 +428,49 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
         s1 += fin[NW + q];
         s2 += fin[2 * NW + q];
       }
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + it.stat_slot) * 3;
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + stat_slot) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;
     }
+  }
+}
+
+// One work item: block `it.block` of the reach group WQ (taps within W = 256 WQ samples), bands
+// [it.band_first, it.band_first + it.band_count) of the launch's list.  DEMOD: Stockwell (circular loads, demodulated
+// outputs).
+template <typename T, int WQ, bool DEMOD, bool COEF, bool BITS>
+__device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
+                                           const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
+                                           cplx<T> w) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  cplx<T> S[16];
+  block_forward<T, DEMOD>(a.sig + (int64_t)blockIdx.z * a.n, a.n, (int64_t)it.block * (kBlk - 512 * WQ) - 256 * WQ, S, buf, tw256,
+                          w, tid, col);
+  block_bands<T, WQ, DEMOD, COEF, BITS>(a, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, S, buf, tw256,
+                                        s_red, w);
+}
+
+// qi_cwt_stx: the Stockwell bands (a2) and the styx bands (a0) of the same block from ONE forward transform -- inside
+// the record its wrapped and its zero-extended loads are the same samples; the blocks that reach over a record end are
+// transformed a second time.
+template <typename T, int WQ, bool COEF, bool BITS>
+__device__ __forceinline__ void dual_item(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem& it,
+                                          cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
+                                          double (*s_red)[kBlkThreads / kWave], cplx<T> w) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  const int64_t n = a0.n, t0 = (int64_t)it.block * (kBlk - 512 * WQ) - 256 * WQ;
+  const bool inside = t0 >= 0 && t0 + kBlk <= n;
+  const T* sig = a0.sig + (int64_t)blockIdx.z * n;
+  cplx<T> S[16];
+  if (it.count2 > 0 || inside) block_forward<T, true>(sig, n, t0, S, buf, tw256, w, tid, col);
+  if (it.count2 > 0)
+    block_bands<T, WQ, true, COEF, BITS>(a2, it.block, it.first2, it.count2, it.plane2, it.slot2, S, buf, tw256, s_red, w);
+  if (it.count0 > 0) {
+    if (!inside) block_forward<T, false>(sig, n, t0, S, buf, tw256, w, tid, col);
+    block_bands<T, WQ, false, COEF, BITS>(a0, it.block, it.first0, it.count0, it.plane0, it.slot0, S, buf, tw256, s_red, w);
   }
 }
 
@@ -560,6 +602,43 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
     case 1: block_item<T, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
     case 2: block_item<T, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
     default: block_item<T, 4, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+  }
+}
+
+template <typename T, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockArgs<T> a0, BlockArgs<T> a2,
+                                                                         const DualItem* __restrict__ items) {
+  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> tw256[256];
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x;
+  {
+    float s, c;
+    sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+    tw256[tid] = mk<T>((T)c, (T)s);
+  }
+  cplx<T> w;
+  {
+    float s, c;
+    const int lane = tid & (kWave - 1);
+    const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // block_bands' column order
+    sincospif((float)col * (2.0f / 4096.0f), &s, &c);
+    w = mk<T>((T)c, (T)s);
+  }
+  const DualItem it = items[blockIdx.x];
+  if (it.wq < 0) {
+    const BlockItem e{it.wq, it.block, it.first0, it.count0, it.plane0, it.slot0};
+    switch (-it.wq) {
+      case 1: edge_item<T, 1, COEF, BITS>(a0, e, buf, tw256, w); break;
+      case 2: edge_item<T, 2, COEF, BITS>(a0, e, buf, tw256, w); break;
+      default: edge_item<T, 4, COEF, BITS>(a0, e, buf, tw256, w); break;
+    }
+    return;
+  }
+  switch (it.wq) {
+    case 1: dual_item<T, 1, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+    case 2: dual_item<T, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+    default: dual_item<T, 4, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
   }
 }
 
@@ -714,6 +793,24 @@ int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels
   if (a.nitems + a.nedge_items <= 0) return QI_OK;
   dim3 grid((unsigned)(a.nitems + a.nedge_items), 1, (unsigned)n_channels);
   return demod ? launch_block_v<float, true>(a, grid, st) : launch_block_v<float, false>(a, grid, st);
+}
+
+template <>
+int launch_block_dual<float>(const BlockArgs<float>& a0, const BlockArgs<float>& a2, const DualItem* items, int32_t nitems,
+                             int64_t n_channels, hipStream_t st) {
+  if (nitems <= 0) return QI_OK;
+  const bool coef = a0.coef != nullptr, bits = a0.bits != nullptr;
+  if (coef != (a2.coef != nullptr) || bits != (a2.bits != nullptr) || a0.n != a2.n) {
+    set_error("block engine: the joint launch needs the same panels from both transforms");
+    return QI_ERR_STATE;
+  }
+  dim3 grid((unsigned)nitems, 1, (unsigned)n_channels);
+  if (coef && bits) k_block_dual<float, true, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+  else if (coef) k_block_dual<float, true, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+  else if (bits) k_block_dual<float, false, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+  else k_block_dual<float, false, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
 }
 
 template <>

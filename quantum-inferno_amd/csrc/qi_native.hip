@@ -980,6 +980,57 @@ int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, 
 template <typename T>
 int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                 const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t B,
+                int64_t nblk, int64_t nstat, const int32_t* band_slots, hipStream_t st);
+// two tails (the two transforms of qi_cwt_stx) in one launch: blockIdx.z selects the transform
+template <typename T>
+struct TailPack {
+  const T* part;
+  T* out;
+  int64_t n;
+  int nchunk, nfin;
+  TailFin f;
+};
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_tail2(TailPack<T> p0, TailPack<T> p1) {
+  __shared__ double s[3][256 / kWave];
+  const TailPack<T>& p = blockIdx.z == 0 ? p0 : p1;
+  if ((int)blockIdx.x < p.nfin) {
+    finalize_block(p.f.part_band, p.f.part_stat, p.f.power_band, p.f.stats, p.f.B, p.f.nblk, p.f.nstat, p.f.band_slots,
+                   blockIdx.x, blockIdx.y, s);
+    return;
+  }
+  time_reduce_block<T, VEC>(p.part, p.out, p.n, p.nchunk, nullptr, 0, (int64_t)blockIdx.x - p.nfin,
+                            (int64_t)gridDim.x - p.nfin, blockIdx.y);
+}
+
+template <typename T>
+int launch_tail2(const T* part0, T* out0, int nchunk0, const double* part_band0, const double* part_stat0,
+                 double* power_band0, double* stats0, int64_t B0, int64_t nblk0, int64_t nstat0,
+                 const int32_t* band_slots0, const T* part1, T* out1, int nchunk1, const double* part_band1,
+                 const double* part_stat1, double* power_band1, double* stats1, int64_t B1, int64_t nblk1, int64_t nstat1,
+                 const int32_t* band_slots1, int64_t C, int64_t n, hipStream_t st) {
+  const bool aligned = n % 4 == 0 && reinterpret_cast<uintptr_t>(out0) % 16 == 0 && reinterpret_cast<uintptr_t>(part0) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(out1) % 16 == 0 && reinterpret_cast<uintptr_t>(part1) % 16 == 0;
+  if (!aligned) {
+    if (int rc = launch_tail<T>(part0, out0, C, n, nchunk0, nullptr, 0, part_band0, part_stat0, power_band0, stats0, B0, nblk0,
+                                nstat0, band_slots0, st))
+      return rc;
+    return launch_tail<T>(part1, out1, C, n, nchunk1, nullptr, 0, part_band1, part_stat1, power_band1, stats1, B1, nblk1,
+                          nstat1, band_slots1, st);
+  }
+  TailPack<T> p0{part0, out0, n, nchunk0, (int)B0 + 1, TailFin{part_band0, part_stat0, power_band0, stats0, B0, nblk0, nstat0, band_slots0}};
+  TailPack<T> p1{part1, out1, n, nchunk1, (int)B1 + 1, TailFin{part_band1, part_stat1, power_band1, stats1, B1, nblk1, nstat1, band_slots1}};
+  const int64_t gt = ceil_div(n, 1024) > 4096 ? 4096 : ceil_div(n, 1024);
+  const int nfin = p0.nfin > p1.nfin ? p0.nfin : p1.nfin;
+  dim3 g((unsigned)(gt + nfin), (unsigned)C, 2);
+  k_tail2<T, 4><<<g, 256, 0, st>>>(p0, p1);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <typename T>
+int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
+                const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t B,
                 int64_t nblk, int64_t nstat, const int32_t* band_slots, hipStream_t st) {
   const bool aligned = n % 4 == 0 && reinterpret_cast<uintptr_t>(out) % (4 * sizeof(T)) == 0 &&
                        reinterpret_cast<uintptr_t>(part) % (4 * sizeof(T)) == 0;
@@ -995,6 +1046,9 @@ int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
+template int launch_tail2<float>(const float*, float*, int, const double*, const double*, double*, double*, int64_t, int64_t,
+                                 int64_t, const int32_t*, const float*, float*, int, const double*, const double*, double*,
+                                 double*, int64_t, int64_t, int64_t, const int32_t*, int64_t, int64_t, hipStream_t);
 template int launch_tail<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, const double*,
                                 const double*, double*, double*, int64_t, int64_t, int64_t, const int32_t*, hipStream_t);
 template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, hipStream_t);

@@ -109,6 +109,11 @@ struct BlockItem {  // one workgroup of the block launch
   int32_t plane;       // time_part plane (relative to chunk_base) it writes
   int32_t stat_slot;   // part_stat slot (relative to stat_base)
 };
+struct DualItem {  // one workgroup of the joint block launch of qi_cwt_stx: the styx bands (0) and the Stockwell bands (2)
+  int32_t wq, block;  // of one block; wq < 0: an edge item of the styx table (fields 0 as in BlockItem)
+  int32_t first0, count0, plane0, slot0;
+  int32_t first2, count2, plane2, slot2;
+};
 template <typename T>
 struct BlockArgs {
   int64_t n;
@@ -136,6 +141,10 @@ struct BlockArgs {
 int block_valid(int wq);  // outputs per block for taps within 256 * wq samples
 template <typename T>
 int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st);
+// a0: styx table, a2: Stockwell table; both must agree on which panels (coefficients, bits) are stored
+template <typename T>
+int launch_block_dual(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem* items, int32_t nitems,
+                      int64_t n_channels, hipStream_t st);
 int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,
                             hipStream_t st);
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);
@@ -214,6 +223,12 @@ template <typename T>
 int launch_tail(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,
                 const double* part_band, const double* part_stat, double* power_band, double* stats, int64_t B,
                 int64_t nblk, int64_t nstat, const int32_t* band_slots, hipStream_t st);
+template <typename T>
+int launch_tail2(const T* part0, T* out0, int nchunk0, const double* part_band0, const double* part_stat0,
+                 double* power_band0, double* stats0, int64_t B0, int64_t nblk0, int64_t nstat0,
+                 const int32_t* band_slots0, const T* part1, T* out1, int nchunk1, const double* part_band1,
+                 const double* part_stat1, double* power_band1, double* stats1, int64_t B1, int64_t nblk1, int64_t nstat1,
+                 const int32_t* band_slots1, int64_t C, int64_t n, hipStream_t st);
 template <typename T>
 int launch_even_bins(const cplx<T>* x2, cplx<T>* x1, int64_t C, int64_t n, hipStream_t st);
 template <typename T>
