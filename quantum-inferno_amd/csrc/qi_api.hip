@@ -247,6 +247,8 @@ struct FusedCarry {
   int demod = 0;
   int64_t ct = 0;
   TailCall tail;
+  bool has_zoom = false;  // the gather / coarse / interpolation launches of the CWT run are deferred as well
+  native::ZoomArgs<float> zoom{};
 };
 
 struct qi_plan {
@@ -342,7 +344,8 @@ struct qi_plan {
   native::DualItem* d_dual = nullptr;  // joint block launch of qi_cwt_stx (styx + Stockwell tables), built on first use
   int32_t n_dual = 0;
   bool dual_valid = false;
-  int native_fuse = 2;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one launch each
+  int native_fuse = 3;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
+                               // launch each, 3 also the gather and the coarse stage of the zoom engine
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
@@ -1130,10 +1133,25 @@ int launch_tail_call(const TailCall& t, hipStream_t st) {
                                     t.power_band, t.stats, t.B, t.nbk, t.stat_slots, t.band_slots, st);
 }
 
+int launch_zoom_all(qi_plan* p, const native::ZoomArgs<float>& z, int64_t ct, hipStream_t st) {
+  p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
+  QI_TRY(native::launch_zoom_gather<float>(z, 0, ct, st));
+  QI_TRY(native::launch_zoom_coarse<float>(z, 0, ct, st));
+  p->prof.end(QI_STAGE_ZOOM_COARSE, st);
+  p->prof.begin(st, QI_STAGE_ZOOM);
+  QI_TRY(native::launch_zoom<float>(z, ct, st));
+  p->prof.end(QI_STAGE_ZOOM, st);
+  return QI_OK;
+}
+
 // the deferred launches of a CWT run, on their own
 int flush_carry(qi_plan* p, FusedCarry* c, hipStream_t st) {
   if (!c || !c->active) return QI_OK;
   c->active = false;
+  if (c->has_zoom) {
+    c->has_zoom = false;
+    QI_TRY(launch_zoom_all(p, c->zoom, c->ct, st));
+  }
   p->prof.begin(st, QI_STAGE_BLOCK);
   QI_TRY(native::launch_block<float>(c->blk, c->demod, c->ct, st));
   p->prof.end(QI_STAGE_BLOCK, st);
@@ -1508,12 +1526,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.chunk_total = chunk_total;
       z.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
-      p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-      QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
-      QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
       z.split_part = zadd;
       z.split_rows = nsplit;
-      p->prof.end(QI_STAGE_ZOOM_COARSE, st);
       int first = 0, chunk0 = 0;
       for (int g = 0; g < NL; ++g) {
         z.lvl_first[g] = first;
@@ -1525,9 +1539,33 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         first += zt.zoom_count[g];
         chunk0 += znchunk[g];
       }
-      p->prof.begin(st, QI_STAGE_ZOOM);
-      QI_TRY(native::launch_zoom<T>(z, ct, st));
-      p->prof.end(QI_STAGE_ZOOM, st);
+      if (deferring && p->native_fuse > 2) {  // the Stockwell run of qi_cwt_stx launches them with its own
+        defer->zoom = z;
+        defer->has_zoom = true;
+        defer->ct = ct;
+      } else {
+        const bool joint = finishing && finish->has_zoom && finish->ct == ct;
+        p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
+        if (joint) {
+          QI_TRY(native::launch_zoom_gather2<T>(finish->zoom, z, ct, st));
+          QI_TRY(native::launch_zoom_coarse2<T>(finish->zoom, z, ct, st));
+        } else {
+          QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
+          QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
+        }
+        p->prof.end(QI_STAGE_ZOOM_COARSE, st);
+        p->prof.begin(st, QI_STAGE_ZOOM);
+        if (joint) {
+          QI_TRY(native::launch_zoom<T>(finish->zoom, ct, st));
+          finish->has_zoom = false;
+        }
+        QI_TRY(native::launch_zoom<T>(z, ct, st));
+        p->prof.end(QI_STAGE_ZOOM, st);
+      }
+    }
+    if (finishing && finish->has_zoom) {  // (this table has no zoom band, or another tiling: the deferred launches alone)
+      QI_TRY(launch_zoom_all(p, finish->zoom, finish->ct, st));
+      finish->has_zoom = false;
     }
     // (the edge items of the block launch finish the split bands the zoom launch began: it comes after it)
     if (blocks && !overlap) QI_TRY(launch_blocks(st));
@@ -2118,6 +2156,7 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
   QI_REQUIRE(bank == QI_BANK_STYX, "qi_cwt_stx runs the styx bank (bank %d given)", bank);
   const bool fuse = p->native_fuse && p->nat[bank].ready && p->nat[2].ready;
   p->carry.active = false;
+  p->carry.has_zoom = false;
   QI_REQUIRE(C > 0, "n_channels must be positive");
   if (fuse) {
     DeviceGuard g0(p->d.device);

@@ -646,12 +646,12 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
 // twiddled baseband bins that k_zoom_gather left in plane tau1 of the band, in place: afterwards
 // plane tau1 of the band holds the envelope samples tau = P tau2 + tau1 of its coarse grid at [tau2].
 template <typename T>
-__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
+__device__ __forceinline__ void zoom_coarse_plane(cplx<T>* __restrict__ plane0) {
   __shared__ cplx<T> buf[16 * kBlkPad];
   __shared__ cplx<T> tw256[256];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
-  cplx<T>* __restrict__ plane = a.coarse + ((int64_t)blockIdx.z * a.planes + blockIdx.x) * kBlk + col;
+  cplx<T>* __restrict__ plane = plane0 + col;
   cplx<T> v[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) v[b] = plane[256 * b];
@@ -669,6 +669,18 @@ __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
   fft4096<T, 1>(v, buf, tw256, w, tid, col);
 #pragma unroll
   for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
+  zoom_coarse_plane<T>(a.coarse + ((int64_t)blockIdx.z * a.planes + blockIdx.x) * kBlk);
+}
+// qi_cwt_stx: the planes of both tables in one launch
+template <typename T>
+__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse2(ZoomArgs<T> a0, ZoomArgs<T> a2) {
+  const bool first = blockIdx.x < (uint32_t)a0.planes;
+  const ZoomArgs<T>& a = first ? a0 : a2;
+  const int64_t plane = first ? blockIdx.x : blockIdx.x - (uint32_t)a0.planes;
+  zoom_coarse_plane<T>(a.coarse + ((int64_t)blockIdx.z * a.planes + plane) * kBlk);
 }
 
 // taps of a Gabor atom as a 4096-point circular-convolution kernel: g[(-u) mod 4096] = conj(psi(u + 1/2)), |u| <= W
@@ -819,6 +831,14 @@ int launch_zoom_coarse<float>(const ZoomArgs<float>& a, int max_level, int64_t n
   (void)max_level;
   dim3 grid((unsigned)a.planes, 1, (unsigned)n_channels);  // every plane of every band is one 4096-point transform
   k_zoom_coarse<float><<<grid, kBlkThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_zoom_coarse2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, int64_t n_channels, hipStream_t st) {
+  dim3 grid((unsigned)(a0.planes + a2.planes), 1, (unsigned)n_channels);
+  k_zoom_coarse2<float><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

@@ -213,6 +213,11 @@ template <typename T>
 int launch_zoom_coarse(const ZoomArgs<T>& a, int max_level, int64_t n_channels, hipStream_t st);  // their 4096-point transforms, in place (qi_block.hip)
 template <typename T>
 int launch_zoom(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
+// qi_cwt_stx: gather / coarse stage of the styx table (a0) and the Stockwell table (a2) in one launch each
+template <typename T>
+int launch_zoom_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
+template <typename T>
+int launch_zoom_coarse2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 
 template <typename T>

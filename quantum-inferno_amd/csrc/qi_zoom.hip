@@ -36,11 +36,11 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
 // compact bank, or shifted spectrum x Gaussian).  One thread per (kappa0, tau1), every block r that can hold occupied
 // bins visited; written to the band's planes [tau1][kappa0], transformed in place by the coarse stage.
 template <typename T, bool STX>
-__global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
-  const BandDesc bd = a.bands[a.plane_band[blockIdx.y]];  // blockIdx.y = plane of the record's coarse storage
+__device__ __forceinline__ void zoom_gather_plane(const ZoomArgs<T>& a, const uint32_t plane) {
+  const BandDesc bd = a.bands[a.plane_band[plane]];  // plane of the record's coarse storage
   const int32_t M = (int32_t)((a.Lf / kZoomD) << bd.edge_slot), P = M / kBlk;
   const int32_t kappa0 = (int32_t)(blockIdx.x * 256 + threadIdx.x);
-  const uint32_t tau1 = blockIdx.y - (uint32_t)bd.edge;
+  const uint32_t tau1 = plane - (uint32_t)bd.edge;
   const int32_t e = (int32_t)tau1 * kBlk + kappa0;
   const int64_t ch = blockIdx.z;
   const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
@@ -71,6 +71,16 @@ __global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
   float s, c;
   sincospif(2.0f * (float)(((uint32_t)kappa0 * tau1) & ((uint32_t)M - 1u)) / (float)M, &s, &c);
   a.coarse[((int64_t)ch * a.planes + bd.edge) * kBlk + e] = cmul(acc, mk<T>((T)c, (T)s));
+}
+template <typename T, bool STX>
+__global__ void __launch_bounds__(256) k_zoom_gather(ZoomArgs<T> a) {
+  zoom_gather_plane<T, STX>(a, blockIdx.y);
+}
+// qi_cwt_stx: the planes of the styx table (a0) and of the Stockwell table (a2) in one launch
+template <typename T>
+__global__ void __launch_bounds__(256) k_zoom_gather2(ZoomArgs<T> a0, ZoomArgs<T> a2) {
+  if (blockIdx.y < (uint32_t)a0.planes) zoom_gather_plane<T, false>(a0, blockIdx.y);
+  else zoom_gather_plane<T, true>(a2, blockIdx.y - (uint32_t)a0.planes);
 }
 
 // Fine stage of one level.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands
@@ -277,6 +287,18 @@ int launch_zoom_gather<float>(const ZoomArgs<float>& a, int max_level, int64_t n
   dim3 grid((unsigned)(kBlk / 256), (unsigned)a.planes, (unsigned)n_channels);
   if (a.stx) k_zoom_gather<float, true><<<grid, 256, 0, st>>>(a);
   else k_zoom_gather<float, false><<<grid, 256, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_zoom_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, int64_t n_channels, hipStream_t st) {
+  if (a0.stx || !a2.stx || a0.nbands <= 0 || a2.nbands <= 0) {
+    set_error("zoom engine: the joint gather takes a styx table and a Stockwell table");
+    return QI_ERR_STATE;
+  }
+  dim3 grid((unsigned)(kBlk / 256), (unsigned)(a0.planes + a2.planes), (unsigned)n_channels);
+  k_zoom_gather2<float><<<grid, 256, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
