@@ -344,8 +344,8 @@ struct qi_plan {
   native::DualItem* d_dual = nullptr;  // joint block launch of qi_cwt_stx (styx + Stockwell tables), built on first use
   int32_t n_dual = 0;
   bool dual_valid = false;
-  int native_fuse = 3;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
-                               // launch each, 3 also the gather and the coarse stage of the zoom engine
+  int native_fuse = 4;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
+                               // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
@@ -1555,11 +1555,15 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         }
         p->prof.end(QI_STAGE_ZOOM_COARSE, st);
         p->prof.begin(st, QI_STAGE_ZOOM);
-        if (joint) {
-          QI_TRY(native::launch_zoom<T>(finish->zoom, ct, st));
-          finish->has_zoom = false;
+        const bool joint_fine = joint && p->native_fuse > 3 && (finish->zoom.coef != nullptr) == (z.coef != nullptr) &&
+                                (finish->zoom.bits != nullptr) == (z.bits != nullptr);
+        if (joint_fine) {
+          QI_TRY(native::launch_zoom2<T>(finish->zoom, z, ct, st));
+        } else {
+          if (joint) QI_TRY(native::launch_zoom<T>(finish->zoom, ct, st));
+          QI_TRY(native::launch_zoom<T>(z, ct, st));
         }
-        QI_TRY(native::launch_zoom<T>(z, ct, st));
+        if (joint) finish->has_zoom = false;
         p->prof.end(QI_STAGE_ZOOM, st);
       }
     }

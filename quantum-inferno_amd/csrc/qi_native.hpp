@@ -217,6 +217,8 @@ int launch_zoom(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_zoom_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 template <typename T>
+int launch_zoom2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);  // and the interpolation
+template <typename T>
 int launch_zoom_coarse2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 

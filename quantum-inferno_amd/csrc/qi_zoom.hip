@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_zoom_gather2(ZoomArgs<T> a0, ZoomArgs<T
 // Fine stage of one level.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands
 // are at baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
 template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS>
-__device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, double (*s_red)[kZoomThreads / kWave],
+__device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int row, double (*s_red)[kZoomThreads / kWave],
                                            double (*s_fin)[kZoomThreads / kWave]) {
   constexpr int NW = kZoomThreads / kWave, S = zoom_span(LEVEL), TAPS = zoom_taps(LEVEL), STEPS = zoom_steps(LEVEL);
   if ((int64_t)blockIdx.x >= a.n / ((int64_t)kZoomD * STEPS * NW)) return;  // this level has fewer groups along time
@@ -219,7 +219,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, doub
 
   T tot = T(0);
   char* __restrict__ time_row = reinterpret_cast<char*>(
-      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * a.n : nullptr);
+      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + row) * a.n : nullptr);
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     tot += colp[s];
@@ -250,17 +250,32 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, doub
   }
 }
 
-// one launch for every level: blockIdx.y selects (level, chunk of the level's band list)
+// row y of a table's fine launch = (level, chunk of the level's band list)
+template <typename T, bool PHASOR, bool COEF, bool BITS>
+__device__ __forceinline__ void zoom_row(const ZoomArgs<T>& a, int y, double (*s_red)[kZoomThreads / kWave],
+                                         double (*s_fin)[kZoomThreads / kWave]) {
+  if (y < a.lvl_chunk0[0] + a.lvl_nchunk[0]) zoom_level<T, 0, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[0], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[1], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[2], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[3], y, s_red, s_fin);
+  else zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], y, s_red, s_fin);
+}
+
+// one launch for every level: blockIdx.y is the row
 template <typename T, bool PHASOR, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   __shared__ double s_red[2][kZoomThreads / kWave];
   __shared__ double s_fin[3][kZoomThreads / kWave];
-  const int y = blockIdx.y;
-  if (y < a.lvl_chunk0[0] + a.lvl_nchunk[0]) zoom_level<T, 0, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[0], s_red, s_fin);
-  else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[1], s_red, s_fin);
-  else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[2], s_red, s_fin);
-  else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[3], s_red, s_fin);
-  else zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], s_red, s_fin);
+  zoom_row<T, PHASOR, COEF, BITS>(a, blockIdx.y, s_red, s_fin);
+}
+
+// qi_cwt_stx: the rows of the styx table (a0, with carrier) and of the Stockwell table (a2) in one launch
+template <typename T, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kZoomThreads) k_zoom2(ZoomArgs<T> a0, ZoomArgs<T> a2, int rows0) {
+  __shared__ double s_red[2][kZoomThreads / kWave];
+  __shared__ double s_fin[3][kZoomThreads / kWave];
+  if ((int)blockIdx.y < rows0) zoom_row<T, true, COEF, BITS>(a0, blockIdx.y, s_red, s_fin);
+  else zoom_row<T, false, COEF, BITS>(a2, (int)blockIdx.y - rows0, s_red, s_fin);
 }
 
 template <typename T, bool PHASOR>
@@ -303,8 +318,8 @@ int launch_zoom_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>&
   return QI_OK;
 }
 
-template <>
-int launch_zoom<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+// grid of a table's fine launch: workgroups along time (the level with the most) x rows
+static int zoom_grid(const ZoomArgs<float>& a, int64_t* groups_out, int* rows_out) {
   int64_t groups = 0;
   int chunks = 0;
   for (int g = 0; g < kZoomLevels; ++g) {
@@ -318,9 +333,39 @@ int launch_zoom<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t
     if (gg > groups) groups = gg;
     chunks = a.lvl_chunk0[g] + a.lvl_nchunk[g];
   }
+  *groups_out = groups;
+  *rows_out = chunks;
+  return QI_OK;
+}
+
+template <>
+int launch_zoom<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+  int64_t groups = 0;
+  int chunks = 0;
+  if (int rc = zoom_grid(a, &groups, &chunks)) return rc;
   if (chunks <= 0) return QI_OK;
   dim3 grid((unsigned)groups, (unsigned)chunks, (unsigned)n_channels);
   return a.stx ? launch_zoom_v<float, false>(a, grid, st) : launch_zoom_v<float, true>(a, grid, st);
+}
+
+template <>
+int launch_zoom2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, int64_t n_channels, hipStream_t st) {
+  int64_t g0 = 0, g2 = 0;
+  int r0 = 0, r2 = 0;
+  if (int rc = zoom_grid(a0, &g0, &r0)) return rc;
+  if (int rc = zoom_grid(a2, &g2, &r2)) return rc;
+  const bool coef = a0.coef != nullptr, bits = a0.bits != nullptr;
+  if (a0.stx || !a2.stx || r0 <= 0 || r2 <= 0 || coef != (a2.coef != nullptr) || bits != (a2.bits != nullptr)) {
+    set_error("zoom engine: the joint launch takes a styx table and a Stockwell table with the same panels");
+    return QI_ERR_STATE;
+  }
+  dim3 grid((unsigned)(g0 > g2 ? g0 : g2), (unsigned)(r0 + r2), (unsigned)n_channels);
+  if (coef && bits) k_zoom2<float, true, true><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
+  else if (coef) k_zoom2<float, true, false><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
+  else if (bits) k_zoom2<float, false, true><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
+  else k_zoom2<float, false, false><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
 }
 
 // Interpolation weights of lane L for window sample j of a wave-step at `level`: the lane sits x = (L - e) / D coarse
