@@ -325,6 +325,7 @@ struct qi_plan {
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_max_level = 3;  // finest coarse grid the zoom engine may use (level 4 costs more in the coarse stage than two-pass saves)
   int native_zoom_waves = 2048; // native_zoom_wgs = 0: waves each level of a zoom launch should have at least
+  int native_zoom_wgs_joint = 768;   // the same budget per table in the joint launch of qi_cwt_stx (512 .. 1024 measured within 1.5 %)
   int native_zoom_wgs = 0;      // > 0: workgroups of a zoom launch, dealt to the levels by work (measured: 1.5 % slower than the per-level rule)
   float* d_zoom_w[native::kZoomLevels][2] = {};  // interpolation weights [level][lane offset]
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
@@ -1225,7 +1226,11 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       znchunk[g] = 1;
       wgs += zgroups[g] * C;
     }
-    if (p->native_zoom_wgs > 0) {
+    // (in the joint launch of qi_cwt_stx the rows of both tables queue behind each other: there the split by work wins,
+    // measured 3 %; in a launch of one table the per-level rule does, 1.5 %)
+    const int64_t zoom_wgs = p->native_zoom_wgs > 0 ? p->native_zoom_wgs
+                             : ((defer || (finish && finish->active)) && p->native_fuse > 3 ? p->native_zoom_wgs_joint : 0);
+    if (zoom_wgs > 0) {
       for (;;) {
         int best = -1;
         double best_load = 0.0;
@@ -1237,7 +1242,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
             best = g;
           }
         }
-        if (best < 0 || wgs + zgroups[best] * C > p->native_zoom_wgs) break;
+        if (best < 0 || wgs + zgroups[best] * C > zoom_wgs) break;
         // (a level that cannot grow any more but carries the largest load ends the search: more rows elsewhere would
         // not shorten the launch)
         bool is_max = true;
@@ -1813,6 +1818,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_ZOOM_WGS_JOINT")) p->native_zoom_wgs_joint = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
