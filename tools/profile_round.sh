@@ -12,8 +12,9 @@ cd $GRAFT_REPO_ROOT
 cp $(ls $out/stats/*/*kernel_stats.csv | tail -1) $out/kernel_stats.csv && rm -rf $out/stats
 tools/traffic.sh traffic_$tag || exit 1
 python tools/traffic_summary.py gpurun_out/traffic_$tag > $out/traffic_summary.txt
-python tools/traffic_summary.py gpurun_out/traffic_$tag --json "zoom:f32:n20:o3:c1" "k_zoom<" | tail -1 > $out/traffic_zoom.json
-python tools/traffic_summary.py gpurun_out/traffic_$tag --json "block:f32:n20:o3:c1" "k_block<" | tail -1 > $out/traffic_block.json
+# (the bench step is qi_cwt_stx: its joint launches are k_zoom2 / k_block_dual)
+python tools/traffic_summary.py gpurun_out/traffic_$tag --json "zoom:f32:n20:o3:c1" "k_zoom2<" | tail -1 > $out/traffic_zoom.json
+python tools/traffic_summary.py gpurun_out/traffic_$tag --json "block:f32:n20:o3:c1" "k_block_dual<" | tail -1 > $out/traffic_block.json
 for c in FETCH_SIZE WRITE_SIZE; do cp $(ls gpurun_out/traffic_$tag/$c/*/*counter_collection.csv | tail -1) $out/${c}_counter_collection.csv; done
 rm -rf gpurun_out/traffic_$tag
 ls -la $out
