@@ -122,17 +122,24 @@ def main():
     plan.set_stx_bands(order, fs)
     sig = torch.from_numpy(synth.channels(n, fs, first, n_ch, total_ch, np.float32 if tdtype == torch.float32 else np.float64)).to(dev)
 
-    # the reduced products of both transforms live in one buffer: the message of the gather, no packing copy
+    # the reduced products of both transforms live in one buffer: the message of the gather, no packing copy.  With more
+    # than one rank the gather of step k overlaps the transforms of step k + 1 (two sets of outputs, used in turn).
     slots = qdist.reduced_slots(n_ch, n_b, n, tdtype)
-    message = torch.empty(2 * slots, dtype=torch.float64, device=dev)
-    out_c, out_s = plan.cwt_stx(sig, coef=True, reductions=True, reduced_out=(message[:slots], message[slots:]))
+    depth = 2 if world > 1 else 1
+    messages = [torch.empty(2 * slots, dtype=torch.float64, device=dev) for _ in range(depth)]
+    outs = [plan.cwt_stx(sig, coef=True, reductions=True, reduced_out=(m[:slots], m[slots:])) for m in messages]
+    pipe = qdist.GatherPipeline(depth=depth, dst=0)
 
     def step():
-        plan.cwt_stx(sig, out=(out_c, out_s))  # qi_cwt_stx: both transforms of the same records in one call
-        flat = qdist.pack_reduced([out_c, out_s])
-        return qdist.gather_reduced(flat, 0) if world > 1 else flat
+        if world == 1:
+            plan.cwt_stx(sig, out=outs[0])  # qi_cwt_stx: both transforms of the same records in one call
+            return qdist.pack_reduced(list(outs[0]))
+        i = pipe.acquire()
+        plan.cwt_stx(sig, out=outs[i])
+        return pipe.submit(i, qdist.pack_reduced(list(outs[i])))
 
     def fence():
+        pipe.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -67,19 +67,60 @@ def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):
 _GATHER_BUFFERS = {}
 
 
-def gather_reduced(flat, dst=0, group=None):
+def gather_reduced(flat, dst=0, group=None, async_op=False, slot=0):
     """Gather equal-sized reduced buffers to `dst`; returns [world, len] there, None elsewhere.  The receive buffer is
-    kept between calls (one [world, len] allocation per shape), the ranks' messages land in its rows directly."""
+    kept between calls (one [world, len] allocation per shape and `slot`), the ranks' messages land in its rows directly.
+    async_op: returns (buffer or None, work) without waiting -- `work.wait()` before `flat` is written again or the
+    buffer is read (see GatherPipeline)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return flat.unsqueeze(0)
+        return (flat.unsqueeze(0), None) if async_op else flat.unsqueeze(0)
     world = dist.get_world_size(group)
+    out, rows = None, None
     if dist.get_rank(group) == dst:
-        key = (flat.numel(), flat.dtype, flat.device, world)
+        key = (flat.numel(), flat.dtype, flat.device, world, slot)
         out = _GATHER_BUFFERS.get(key)
         if out is None:
-            _GATHER_BUFFERS.clear()
+            for k in [k for k in _GATHER_BUFFERS if k[:4] != key[:4]]:
+                del _GATHER_BUFFERS[k]
             out = _GATHER_BUFFERS[key] = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
-        dist.gather(flat, list(out.unbind(0)), dst=dst, group=group)
-        return out
-    dist.gather(flat, None, dst=dst, group=group)
-    return None
+        rows = list(out.unbind(0))
+    work = dist.gather(flat, rows, dst=dst, group=group, async_op=async_op)
+    return (out, work) if async_op else out
+
+
+class GatherPipeline:
+    """The gather of step k overlaps the transforms of step k + 1: `depth` message buffers are used in turn, and a
+    buffer's gather is waited for (on the stream, not the host, with RCCL) just before the buffer is written again.
+
+        pipe = GatherPipeline(depth=2)
+        for k in range(steps):
+            i = pipe.acquire()            # waits for the gather that last used buffer i
+            ... write message[i] ...
+            pipe.submit(i, message[i])    # asynchronous gather to rank `dst`
+        gathered = pipe.drain()           # list of the receive buffers on `dst` (None elsewhere)
+    """
+
+    def __init__(self, depth=2, dst=0, group=None):
+        self.depth, self.dst, self.group = depth, dst, group
+        self.works = [None] * depth
+        self.outs = [None] * depth
+        self.k = 0
+
+    def acquire(self):
+        i = self.k % self.depth
+        if self.works[i] is not None:
+            self.works[i].wait()
+            self.works[i] = None
+        return i
+
+    def submit(self, i, flat):
+        self.outs[i], self.works[i] = gather_reduced(flat, self.dst, self.group, async_op=True, slot=i)
+        self.k += 1
+        return self.outs[i]
+
+    def drain(self):
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
+        return self.outs

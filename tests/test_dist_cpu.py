@@ -45,6 +45,47 @@ def _worker(rank, world, port, total_ch, n_b, n, out_dir):
     dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, steps, length, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quantum_inferno_amd import dist as qdist
+
+    depth = 2
+    messages = [torch.empty(length, dtype=torch.float64) for _ in range(depth)]
+    pipe = qdist.GatherPipeline(depth=depth, dst=0)
+    seen = []
+    for k in range(steps):
+        i = pipe.acquire()  # the gather that last read messages[i] is over: it may be written again
+        if rank == 0 and pipe.outs[i] is not None:
+            seen.append(pipe.outs[i].clone())  # what step k - depth delivered
+        messages[i].copy_(torch.arange(length, dtype=torch.float64) + 1000.0 * rank + 10.0 * k)
+        pipe.submit(i, messages[i])
+    outs = pipe.drain()
+    if rank == 0:
+        torch.save({"seen": seen, "last": [o.clone() for o in outs]}, os.path.join(out_dir, "pipe.pt"))
+    else:
+        assert all(o is None for o in outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipeline_world2(tmp_path):
+    """GatherPipeline (the bench's overlapped gather): every step's message of every rank arrives intact although the
+    buffers are reused every second step."""
+    steps, length, world = 5, 64, 2
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), steps, length, str(tmp_path)), nprocs=world, join=True)
+    got = torch.load(os.path.join(str(tmp_path), "pipe.pt"))
+    base = torch.arange(length, dtype=torch.float64)
+    for k, buf in enumerate(got["seen"]):  # steps 0 .. steps - 3
+        for rank in range(world):
+            assert torch.equal(buf[rank], base + 1000.0 * rank + 10.0 * k)
+    for k in (steps - 2, steps - 1):
+        for rank in range(world):
+            assert torch.equal(got["last"][k % 2][rank], base + 1000.0 * rank + 10.0 * k)
+
+
 def test_shard_partitions_every_channel_once():
     from quantum_inferno_amd import dist as qdist
 
