@@ -154,7 +154,9 @@ int qi_stx(qi_plan* plan, const void* sig, int64_t n_channels, const qi_tfr_out*
 
 /* Both of the above on the same records in one call (bank = QI_BANK_STYX): the results are those of qi_cwt followed by
  * qi_stx to within float rounding -- the Stockwell bands may be formed from the even bins of the zero-padded spectrum
- * the CWT has just made instead of a second forward transform (the tutorials run both on every record,
+ * the CWT has just made instead of a second forward transform, and when the records fit one workspace tile the two
+ * transforms share their kernel launches stage by stage (one forward transform per 4096-sample block for the bands of
+ * both), so out_cwt is complete only when the call's work on `stream` is (the tutorials run both on every record,
  * s04_tone_tfr.py:84-112). */
 int qi_cwt_stx(qi_plan* plan, int bank, const void* sig, int64_t n_channels, const qi_tfr_out* out_cwt,
                const qi_tfr_out* out_stx, qi_stream stream);
