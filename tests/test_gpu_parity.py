@@ -502,6 +502,45 @@ def test_fused_cwt_stx_call_matches_separate_calls():
     plan.close()
 
 
+def test_fused_call_other_requests_and_tiles():
+    """qi_cwt_stx beyond the benchmark's request: reductions only and coefficients + bits through the joint launches
+    (the reductions do not depend on which panels are stored: bit-equal), the two transforms asking for different
+    panels (joint launches where the kernels allow, else one after the other), and a workspace that holds one record
+    at a time (no joint launches: the plain sequence)."""
+    n, fs, order = 1 << 20, 1000.0, 3
+    x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 2, np.float32) for c in range(2)])).cuda()
+    plan = _plan_with_all(n, fs, order, np.float32, channels=2)
+    full_c, full_s = plan.cwt_stx(x, coef=True, bits=True, reductions=True)
+    red_c, red_s = plan.cwt_stx(x, coef=False, bits=False, reductions=True)
+    for full, red in ((full_c, red_c), (full_s, red_s)):
+        assert torch.equal(full.reduced, red.reduced)
+    sep_c = plan.cwt(x, coef=True, bits=True, reductions=True)
+    big = sep_c.coef.abs() >= 1e-2 * float(sep_c.coef.abs().max())
+    assert float((full_c.bits - sep_c.bits).abs()[big].max()) <= 1e-5
+    assert float((full_c.coef - sep_c.coef).abs().max()) <= 2e-6 * float(sep_c.coef.abs().max())
+    # different requests on the two sides of one call (C ABI only: the wrapper passes the same flags to both)
+    import ctypes as C
+    from quantum_inferno_amd import _lib
+    res_c, desc_c = plan._outputs(_lib.QI_BANK_STYX, 2, True, False, True, 1.0, 0.0, None, None)
+    res_s, desc_s = plan._outputs(_lib.QI_TABLE_STX, 2, False, False, True, 1.0, 0.0, None, None)
+    _lib.check(plan._lib.qi_cwt_stx(plan._handle, _lib.QI_BANK_STYX, _lib.ptr(x), 2, C.byref(desc_c), C.byref(desc_s),
+                                    plan._stream()))
+    torch.cuda.synchronize()
+    for res, full in ((res_c, full_c), (res_s, full_s)):  # (other kernels than the joint ones: float rounding)
+        assert torch.allclose(res.power_band, full.power_band, rtol=1e-5)
+        assert torch.allclose(res.power_time, full.power_time, rtol=1e-4, atol=1e-7 * float(full.power_time.max()))
+        assert torch.allclose(res.stats[:, :3], full.stats[:, :3], rtol=1e-5)
+    assert float((res_c.coef - full_c.coef).abs().max()) <= 2e-6 * float(full_c.coef.abs().max())
+    plan.close()
+    small = _plan_with_all(n, fs, order, np.float32, workspace=260 << 20)  # one record's scratch, not two
+    one_c, one_s = small.cwt_stx(x, coef=True, reductions=True)
+    for one, full in ((one_c, full_c), (one_s, full_s)):
+        assert float((one.coef - full.coef).abs().max()) <= 2e-6 * float(full.coef.abs().max())
+        assert torch.allclose(one.power_band, full.power_band, rtol=1e-5)
+        assert torch.allclose(one.stats[:, :3], full.stats[:, :3], rtol=1e-5)
+    small.close()
+
+
 @pytest.mark.parametrize("log2n", [18, 19, 21, 22])
 def test_native_engine_other_lengths(log2n):
     """Stockwell transform and styx CWT at the other power-of-two lengths the native engine takes (their order-3 band
