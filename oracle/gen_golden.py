@@ -186,11 +186,24 @@ def gen_stft():
     save("stft.npz", **d)
 
 
-def panel_digest(panel, rows):
+def time_samples(n, dense=False):
+    """Time samples kept of a long panel row: a regular comb, the middle of the record and -- `dense` (the benchmark
+    length, every band kept) -- both record ends (zero padding / wrap-around act there) and a few samples around
+    multiples of the overlap-save block strides of the block engine (3584, 3072, 2048 outputs per block)."""
+    parts = [np.arange(0, n, max(1, n // 512)), np.arange(n // 2 - 256, n // 2 + 256)]
+    if dense:
+        parts += [np.arange(0, 96), np.arange(n - 96, n)]
+        for stride, k in ((3584, 100), (3072, 171), (2048, 300), (3584, 292), (2048, 511)):
+            parts.append(np.arange(stride * k - 6, stride * k + 6))
+    t = np.unique(np.concatenate(parts))
+    return t[(t >= 0) & (t < n)]
+
+
+def panel_digest(panel, rows, dense=False):
     p = np.abs(panel) ** 2
     sh = tfr_info.shannon_stft_from_tfr_power(p)
     n = panel.shape[1]
-    tsel = np.unique(np.concatenate([np.arange(0, n, max(1, n // 512)), np.arange(n // 2 - 256, n // 2 + 256)]))
+    tsel = time_samples(n, dense)
     return {
         "rows": panel[rows][:, tsel] if n > 8192 else panel[rows],
         "tsel": tsel,
@@ -248,7 +261,39 @@ def gen_shannon1d():
     save("shannon1d.npz", **d)
 
 
-def gen_sized(log2n, orders, fs, name):
+def gen_corners():
+    """Three corners of the path that had no reference vector: the Gaussian-window STFT (styx_fft.py:190-227), chirped
+    atoms index_shift = +-1 (cwt_atoms.py:22,42-44,202-211) and the unit-amplitude dictionary (styx_cwt.py:139)."""
+    d = {}
+    n, fs = 2048, 1000.0
+    for dtype in (np.float64, np.float32):
+        sig = synth_chirp(n, fs, dtype=dtype)
+        tag = np.dtype(dtype).name
+        d[f"sig_{tag}"] = sig
+        f, t, z = styx_fft.gtx_complex_pow2(sig, fs, 256)
+        d[f"gtx_f_{tag}"], d[f"gtx_t_{tag}"], d[f"gtx_z_{tag}"] = f, t, z
+        f, t, z = styx_fft.gtx_complex_pow2(sig, fs, 200, gaussian_sigma=30, overlap_points=150, nfft_points=512)
+        d[f"gtx2_f_{tag}"], d[f"gtx2_t_{tag}"], d[f"gtx2_z_{tag}"] = f, t, z
+    sig = d["sig_float64"]
+    for shift, tag in ((1.0, "p1"), (-1.0, "m1")):
+        c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, 3, index_shift=shift)
+        d[f"shift_cwt_{tag}"], d[f"shift_f_{tag}"] = c, fc
+        if shift > 0:
+            d[f"shift_bits_{tag}"] = bits
+        d[f"shift_mqg_{tag}"] = np.array(cwt_atoms.chirp_mqg_from_n(3, shift))
+    c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, 6, index_shift=1.0, dictionary_type="spect")
+    d["shift_cwt_o6_spect_p1"] = c[::3]
+    for order in (3,):
+        f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs, dictionary_type="unit")
+        d[f"unit_cwt_o{order}"], d[f"unit_f_o{order}"] = cwt, f
+    atoms, t_c, scale, omega, amp = styx_cwt.wavelet_centered_4cwt(3, n, f[:4], fs, "unit")
+    d["unit_atoms"], d["unit_amp"] = atoms, amp[:, 0]
+    save("corners_n2048.npz", **d)
+
+
+def gen_sized(log2n, orders, fs, name, all_rows=False):
+    """all_rows: keep EVERY band (at the sampled times) instead of three, so that each sub-engine of the native path
+    (zoom levels, block reach groups, narrow / wide filter spectra, split bands) is pinned by the reference."""
     d = {}
     n = 2 ** log2n
     sig = synth_chirp(n, fs, dtype=np.float32)
@@ -258,19 +303,20 @@ def gen_sized(log2n, orders, fs, name):
         d["sig_samples"] = sig[:: n // 4096]
     for order in orders:
         f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
-        rows = np.array([0, len(f) // 2, len(f) - 1])
+        rows = np.arange(len(f)) if all_rows else np.array([0, len(f) // 2, len(f) - 1])
         d[f"f_o{order}"], d[f"rows_o{order}"] = f, rows
-        for k, v in panel_digest(cwt, rows).items():
+        for k, v in panel_digest(cwt, rows, all_rows).items():
             d[f"cwt_{k}_o{order}"] = v
         del cwt
+        print(f"  n=2^{log2n} order {order} cwt done", flush=True)
         f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
-        for k, v in panel_digest(stx, rows).items():
+        for k, v in panel_digest(stx, rows, all_rows).items():
             d[f"stx_{k}_o{order}"] = v
         del stx
         c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order)
-        rows_c = np.array([0, len(fc) // 2, len(fc) - 1])
+        rows_c = np.arange(len(fc)) if all_rows else np.array([0, len(fc) // 2, len(fc) - 1])
         d[f"chirp_f_o{order}"], d[f"chirp_rowsel_o{order}"] = fc, rows_c
-        for k, v in panel_digest(c, rows_c).items():
+        for k, v in panel_digest(c, rows_c, all_rows).items():
             d[f"chirp_{k}_o{order}"] = v
         del c, bits
         print(f"  n=2^{log2n} order {order} done", flush=True)
@@ -283,7 +329,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "shannon1d", "stfft", "medium"] + (["large"] if a.large else [])
+    todo = a.only.split(",") if a.only else ["bands", "small", "stft", "stxgen", "shannon1d", "stfft", "corners", "medium"] + (["large"] if a.large else [])
     if "bands" in todo:
         gen_bands()
     if "small" in todo:
@@ -296,8 +342,13 @@ if __name__ == "__main__":
         gen_shannon1d()
     if "stfft" in todo:
         gen_short_time_fft()
+    if "corners" in todo:
+        gen_corners()
     if "medium" in todo:
         gen_sized(13, (3, 12), 1000.0, "medium_n8192.npz")
     if "large" in todo:
         gen_sized(16, (3, 12), 800.0, "large_n65536.npz")
-        gen_sized(20, (3,), 1000.0, "large_n1048576.npz")
+    if "large" in todo or "large20" in todo:
+        gen_sized(20, (3,), 1000.0, "large_n1048576.npz", all_rows=True)
+    if "large12" in todo:  # BASELINE configs[2] per channel: order 12 (167 bands) at 2^20 samples; ~30 GB RSS, ~6 min
+        gen_sized(20, (12,), 1000.0, "large_n1048576_o12.npz", all_rows=True)

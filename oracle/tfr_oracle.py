@@ -201,6 +201,24 @@ def stft_complex_pow2(sig, fs, seg, overlap=None, nfft=None, alpha=0.25):
     return stft_spectral(sig, fs, tukey_periodic(seg, alpha), seg, overlap, nfft)
 
 
+def gaussian_periodic(m, sigma):
+    """scipy.signal.get_window(("gaussian", sigma), m): fftbins=True -> the symmetric (m + 1)-point Gaussian without
+    its last sample (SciPy 1.15.3 signal/windows/_windows.py: gaussian, _extend/_truncate)."""
+    k = np.arange(0, m + 1) - m / 2.0
+    return np.exp(-(k ** 2) / (2 * sigma * sigma))[:-1]
+
+
+def gtx_complex_pow2(sig, fs, seg, sigma=None, overlap=None, nfft=None):
+    """Returns (f, t, Z): the Gaussian-window STFT.  ref: styx_fft.py:190-227."""
+    if nfft is None:
+        nfft = int(2 ** np.ceil(np.log2(seg)))
+    if overlap is None:
+        overlap = int(seg / 2)
+    if sigma is None:
+        sigma = int(seg / 4)
+    return stft_spectral(sig, fs, gaussian_periodic(int(seg), sigma), int(seg), overlap, nfft)
+
+
 def stft_segment_points(fs, order, center_hz=None, octaves_below=4):
     """ref: styx_fft.py:31-41."""
     if center_hz is None:

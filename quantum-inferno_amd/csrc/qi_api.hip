@@ -349,6 +349,7 @@ struct qi_plan {
                                // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
+  int64_t native_tile = 0;     // qi_cwt_stx: at most this many records per joint tile (0: as many as the scratch holds)
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
@@ -1164,7 +1165,10 @@ int flush_carry(qi_plan* p, FusedCarry* c, hipStream_t st) {
 
 template <typename T>
 int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st,
-               bool may_share = false, FusedCarry* defer = nullptr, FusedCarry* finish = nullptr) {
+               bool may_share = false, FusedCarry* defer = nullptr, FusedCarry* finish = nullptr,
+               size_t* probe = nullptr) {
+  // probe: only report the scratch bytes one record needs when this run is the `defer` (CWT) or the `finish`
+  // (Stockwell, spectra shared) half of a joint qi_cwt_stx tile of C records; nothing is launched
   static_assert(std::is_same<T, float>::value, "the native engine is float32");
   struct Sub {
     const qi_plan::NativeTable* t;
@@ -1229,7 +1233,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     // (in the joint launch of qi_cwt_stx the rows of both tables queue behind each other: there the split by work wins,
     // measured 3 %; in a launch of one table the per-level rule does, 1.5 %)
     const int64_t zoom_wgs = p->native_zoom_wgs > 0 ? p->native_zoom_wgs
-                             : ((defer || (finish && finish->active)) && p->native_fuse > 3 ? p->native_zoom_wgs_joint : 0);
+                             : ((defer || (finish && (finish->active || probe))) && p->native_fuse > 3 ? p->native_zoom_wgs_joint : 0);
     if (zoom_wgs > 0) {
       for (;;) {
         int best = -1;
@@ -1299,7 +1303,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // qi_cwt_stx: the Stockwell call can take its spectra from the even bins of the zero-padded spectra the CWT call
   // left at the start of the scratch -- when nothing of this table needs the n-point spectrum as an array (every band
   // on the zoom / block engines) and both calls hold all records in one tile
-  bool share = may_share && kind == 2 && p->shared_valid && p->shared_sig == sig_v && p->shared_C == C &&
+  bool share = may_share && kind == 2 && (probe || (p->shared_valid && p->shared_sig == sig_v && p->shared_C == C)) &&
                p->nat[kind].h_rows.empty() && !shorts;
   const size_t e_x = (size_t)(share ? 2 * Lf0 : Lf0) * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
@@ -1314,6 +1318,10 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   const int32_t nsplit = kind == 0 ? p->nsplit : 0;  // split bands: the zoom launch hands its part to the block launch
   const size_t e_add = (size_t)nsplit * n * sizeof(cplx<T>);
   const size_t per_chan = e_x + e_xn + e_imd + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_zc + e_add;
+  if (probe) {
+    *probe = per_chan;
+    return QI_OK;
+  }
   if (p->ws_bytes < per_chan + 4096) {
     set_error("workspace of %zu bytes cannot hold one record's native scratch of %zu bytes", p->ws_bytes,
               per_chan + 4096);
@@ -1827,6 +1835,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
   if (const char* e = getenv("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_TILE")) p->native_tile = atoll(e);
   if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
@@ -2160,6 +2169,18 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
 }
 
+// the outputs of records [c0, ...) of a call whose panels have B bands
+static qi_tfr_out shift_out(const qi_tfr_out& o, int64_t c0, int64_t B, int64_t n, int dtype) {
+  const size_t r = dtype == QI_F64 ? 8 : 4;
+  qi_tfr_out s = o;
+  if (o.coef) s.coef = static_cast<char*>(o.coef) + (size_t)c0 * B * n * 2 * r;
+  if (o.bits) s.bits = static_cast<char*>(o.bits) + (size_t)c0 * B * n * r;
+  if (o.power_band) s.power_band = static_cast<char*>(o.power_band) + (size_t)c0 * B * 8;
+  if (o.power_time) s.power_time = static_cast<char*>(o.power_time) + (size_t)c0 * n * r;
+  if (o.stats) s.stats = static_cast<char*>(o.stats) + (size_t)c0 * 4 * 8;
+  return s;
+}
+
 int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* out_cwt, const qi_tfr_out* out_stx,
                qi_stream stream) {
   QI_REQUIRE(p && sig && out_cwt && out_stx, "null argument");
@@ -2168,22 +2189,50 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
   p->carry.active = false;
   p->carry.has_zoom = false;
   QI_REQUIRE(C > 0, "n_channels must be positive");
+  hipStream_t st = (hipStream_t)stream;
   if (fuse) {
+    // Joint launches need the scratch of both transforms of a tile side by side: the records go through in tiles of
+    // as many as fit (the scratch per record depends a little on the tile's size -- rows of the zoom launch --, so the
+    // size is settled by iteration; it only ever shrinks).
     DeviceGuard g0(p->d.device);
-    p->prof.unchain();
-    QI_TRY(run_native<float>(p, bank, sig, C, out_cwt, (hipStream_t)stream, false, &p->carry, nullptr));
-  } else {
-    QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
-  }
-  DeviceGuard g(p->d.device);
-  p->prof.unchain();
-  if (p->nat[2].ready) {
-    int rc = run_native<float>(p, 2, sig, C, out_stx, (hipStream_t)stream, /*may_share=*/p->nat[bank].ready, nullptr,
-                               &p->carry);
-    if (p->carry.active) {  // the Stockwell run failed before it reached the deferred launches
-      const int rc2 = flush_carry(p, &p->carry, (hipStream_t)stream);
-      if (rc == QI_OK) rc = rc2;
+    int64_t tile = C;
+    if (p->native_tile > 0 && tile > p->native_tile) tile = p->native_tile;
+    for (int it = 0; it < 8 && tile >= 1; ++it) {
+      size_t pc0 = 0, pc2 = 0;
+      QI_TRY(run_native<float>(p, bank, sig, tile, out_cwt, st, false, &p->carry, nullptr, &pc0));
+      QI_TRY(run_native<float>(p, 2, sig, tile, out_stx, st, true, nullptr, &p->carry, &pc2));
+      const int64_t fit = p->ws_bytes > (1u << 16) ? (int64_t)((p->ws_bytes - (1u << 16)) / (pc0 + pc2)) : 0;
+      if (fit >= tile) break;
+      tile = fit;
     }
+    if (tile >= 1) {
+      const int64_t n = p->n, B0 = p->nb[bank], B2 = p->nb_stx;
+      const size_t r = p->d.dtype == QI_F64 ? 8 : 4;
+      for (int64_t c0 = 0; c0 < C; c0 += tile) {
+        const int64_t ct = C - c0 < tile ? C - c0 : tile;
+        const void* s = static_cast<const char*>(sig) + (size_t)c0 * n * r;
+        const qi_tfr_out oc = shift_out(*out_cwt, c0, B0, n, p->d.dtype), os = shift_out(*out_stx, c0, B2, n, p->d.dtype);
+        p->carry.active = false;
+        p->carry.has_zoom = false;
+        p->prof.unchain();
+        QI_TRY(run_native<float>(p, bank, s, ct, &oc, st, false, &p->carry, nullptr));
+        p->prof.unchain();
+        int rc = run_native<float>(p, 2, s, ct, &os, st, /*may_share=*/true, nullptr, &p->carry);
+        if (p->carry.active) {  // the Stockwell run failed before it reached the deferred launches
+          const int rc2 = flush_carry(p, &p->carry, st);
+          if (rc == QI_OK) rc = rc2;
+        }
+        p->shared_valid = false;
+        QI_TRY(rc);
+      }
+      return QI_OK;
+    }
+  }
+  QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
+  if (p->nat[bank].ready && p->nat[2].ready) {  // separate launches, but the Stockwell run may still use the CWT's spectra
+    DeviceGuard g(p->d.device);
+    p->prof.unchain();
+    const int rc = run_native<float>(p, 2, sig, C, out_stx, st, /*may_share=*/true, nullptr, nullptr);
     p->shared_valid = false;
     return rc;
   }

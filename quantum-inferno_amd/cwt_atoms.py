@@ -168,8 +168,8 @@ def cwt_chirp_complex(
     plan = engine.cached_plan(key, make)
     res = plan._run(which, sig, True, True, False, 1.0, 0.0)
     return (
-        engine.finish(res.coef, was_numpy, was_1d),
-        engine.finish(res.bits, was_numpy, was_1d),
+        engine.finish(res.coef, was_numpy, was_1d, widen=True),
+        engine.finish(res.bits, was_numpy, was_1d, widen=True),
         np.arange(n) / fs,
         res.frequency_hz,
     )

@@ -362,9 +362,26 @@ def gabor_atoms(n, p_re, p_im, omega, amp, device=None):
     return out
 
 
-def finish(result_tensor, was_numpy, was_1d):
-    """Undo as_signal's batching / device move on an output."""
+# What the reference-signature wrappers hand back to NumPy callers for float32 records.  The reference returns
+# complex128 panels (float64 bits) whatever the record's dtype (styx_cwt.py:195-198, styx_stx.py:228,
+# cwt_atoms.py:408): "reference" computes in float32 and widens on the way out, so a drop-in caller sees the
+# reference's dtypes; "native" keeps complex64 / float32 (half the host memory and copy time).  CUDA tensors in ->
+# tensors out are never widened.
+NUMPY_RESULT_DTYPE = "reference"
+
+
+def finish(result_tensor, was_numpy, was_1d, widen=False):
+    """Undo as_signal's batching / device move on an output.  widen: a panel the reference would return in double
+    precision (see NUMPY_RESULT_DTYPE)."""
     if result_tensor is None:
         return None
     t = result_tensor[0] if was_1d else result_tensor
-    return t.cpu().numpy() if was_numpy else t
+    if not was_numpy:
+        return t
+    a = t.cpu().numpy()
+    if widen and NUMPY_RESULT_DTYPE == "reference":
+        if a.dtype == np.complex64:
+            a = a.astype(np.complex128)
+        elif a.dtype == np.float32:
+            a = a.astype(np.float64)
+    return a

@@ -109,7 +109,8 @@ def cwt_complex_any_scale_pow2(
     """Order-N Gabor CWT of one record, or of every row of a [channels x n] batch (ref styx_cwt.py:147-198).
 
     NumPy in -> NumPy out; CUDA tensor in -> CUDA tensors out.  float64 input is computed in
-    float64 / complex128 as the reference does, float32 input in float32 / complex64.
+    float64 / complex128 as the reference does, float32 input in float32 and -- for NumPy callers -- widened to
+    the reference's complex128 on the way out (engine.NUMPY_RESULT_DTYPE).
 
     :return: frequency_cwt_hz [B], time_cwt_s [n], cwt [B x n] (or [channels x B x n])
     """
@@ -130,4 +131,4 @@ def cwt_complex_any_scale_pow2(
     plan = engine.cached_plan(key, make)
     res = plan.cwt(sig, coef=True)
     time_cwt_s = np.arange(n) / fs
-    return res.frequency_hz, time_cwt_s, engine.finish(res.coef, was_numpy, was_1d)
+    return res.frequency_hz, time_cwt_s, engine.finish(res.coef, was_numpy, was_1d, widen=True)

@@ -82,6 +82,57 @@ def _stft_windowed(sig_wf, fs, window64, segment_points, overlap_points, nfft_po
     return freq_hz, time_s, engine.finish(z, was_numpy, was_1d), engine.finish(bits, was_numpy, was_1d)
 
 
+class StftPlan:
+    """stft_from_sig for batches of records of one shape with every buffer kept between calls (window on the device,
+    outputs, scratch): the per-call work is the kernels alone.  Results are those of stft_from_sig (ref
+    styx_fft.py:14-57); `run` returns (stft_complex [C, nfft/2+1, segments], stft_bits)."""
+
+    def __init__(self, n, channels, frequency_sample_rate_hz, band_order_nth, dtype=torch.float32, device=None):
+        self._lib = _lib.require_gpu()
+        self.n, self.channels, self.fs = int(n), int(channels), float(frequency_sample_rate_hz)
+        self.seg = stft_segment_points(self.fs, band_order_nth)
+        if self.n < self.seg:
+            raise ValueError(f"Signal length: {self.n} is less than time_fft_nd: {self.seg}")
+        self.hop, self.nfft = self.seg // 2, self.seg
+        self.rdtype = engine._real_dtype(dtype)
+        self.device = torch.device(device) if device is not None else engine.default_device()
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        f64 = self.rdtype == torch.float64
+        win64 = tukey_window_periodic(self.seg, 1.0)
+        win = win64 if f64 else win64.astype(np.float32)
+        self.scale = float(np.sqrt(1.0 / np.sum(win.astype(np.float64)) ** 2)) * 2 * np.sqrt(np.pi) / self.seg
+        self.window = torch.from_numpy(np.ascontiguousarray(win)).to(self.device)
+        self.n_seg = int(self._lib.qi_stft_segments(self.n, self.seg, self.hop))
+        self.n_f = self.nfft // 2 + 1
+        self.code = _lib.QI_F64 if f64 else _lib.QI_F32
+        self.z = torch.empty((self.channels, self.n_f, self.n_seg), dtype=engine._complex_of(self.rdtype), device=self.device)
+        self.bits = torch.empty((self.channels, self.n_f, self.n_seg), dtype=self.rdtype, device=self.device)
+        self.scratch_bytes = int(self._lib.qi_stft_scratch_bytes(self.code, self.channels, self.n, self.seg, self.hop, self.nfft))
+        self.scratch = torch.empty(max(self.scratch_bytes, 1), dtype=torch.uint8, device=self.device)
+        padded = self.n + 2 * (self.seg // 2)
+        padded += (-(padded - self.seg) % self.hop) % self.seg
+        self.time_s = np.arange(self.seg / 2, padded - self.seg / 2 + 1, self.hop) / float(self.fs) - (self.seg / 2) / self.fs
+        self.frequency_hz = np.fft.rfftfreq(self.nfft, 1 / self.fs)
+
+    @property
+    def points(self):
+        """complex coefficients one call produces"""
+        return self.channels * self.n_f * self.n_seg
+
+    def run(self, sig):
+        if sig.shape != (self.channels, self.n) or sig.dtype != self.rdtype or not sig.is_cuda:
+            raise ValueError(f"signal must be a [{self.channels}, {self.n}] {self.rdtype} CUDA tensor")
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self._lib.qi_stft(self.code, self.device.index, _lib.ptr(sig), self.channels, self.n, _lib.ptr(self.window),
+                                  self.seg, self.hop, self.nfft, self.scale, _lib.ptr(self.z), _lib.ptr(self.bits),
+                                  float(get_epsilon()), _lib.ptr(self.scratch), self.scratch_bytes,
+                                  _lib.stream_ptr(self.device))
+            )
+        return self.z, self.bits
+
+
 def stft_complex_pow2(
     sig_wf,
     frequency_sample_rate_hz: float,

@@ -30,7 +30,7 @@ def stx_complex_any_scale_pow2(band_order_nth: float, sig_wf, frequency_sample_r
 
     plan = engine.cached_plan(key, make)
     res = plan.stx(sig, coef=True)
-    return res.frequency_hz, np.arange(n) / fs, engine.finish(res.coef, was_numpy, was_1d)
+    return res.frequency_hz, np.arange(n) / fs, engine.finish(res.coef, was_numpy, was_1d, widen=True)
 
 
 def sig_pad_up_to_pow2(sig_wf: np.ndarray, n_fft: int, verbosity: bool = False):
@@ -126,5 +126,5 @@ def tfr_stx_fft(
         ).to(torch.complex128)
     finally:
         plan.close()
-    conv = (lambda t: t.cpu().numpy()) if was_numpy else (lambda t: t)
+    conv = (lambda t: engine.finish(t, was_numpy, False, widen=True))
     return conv(tfr.contiguous()), conv(psd), frequency_stx, frequency_stx_fft, conv(win)

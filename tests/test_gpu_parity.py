@@ -4,7 +4,8 @@ same seeded inputs, (3) size-independent properties at the benchmark size.
 
 Stated tolerances (max|delta| relative to max|reference| of the panel unless noted):
   float64 path : 1e-10 coefficients, 1e-8 log2 bits where |z| >= 1e-6 max, 1e-10 reductions
-  float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-2 max, 1e-4 reductions
+  float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-3 max, 1e-4 reductions; at the benchmark
+                 length every band is also held to 1e-5 of ITS OWN maximum (weak bands included)
 Band tables, shift indices, STFT shapes / time / frequency axes: bit-exact.
 """
 import os
@@ -22,7 +23,9 @@ from quantum_inferno_amd import cwt_atoms, engine, scales_dyadic, styx_cwt, styx
 pytestmark = pytest.mark.gpu
 
 TOL = {np.float64: dict(coef=1e-10, bits=1e-8, bits_floor=1e-6, red=1e-10),
-       np.float32: dict(coef=2e-5, bits=1e-3, bits_floor=1e-2, red=1e-4)}
+       np.float32: dict(coef=2e-5, bits=1e-3, bits_floor=1e-3, red=1e-4, row=1e-5)}
+# (measured at 2^20 samples against the reference, tools/measure_parity.py: panel-relative error < 1e-6, every band
+# within 2.4e-6 of its own maximum at orders 3 and 12, bits within 3e-4 above 1e-3 of the panel maximum)
 
 
 # The medium / large fixtures were captured from a float32 record: SciPy then evaluates the signal's
@@ -46,12 +49,13 @@ def test_small_panels_vs_reference(golden, key, order, fs, dtype):
     sig = g[f"sig_{key}"].astype(dtype)
     f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
     assert np.array_equal(f, g[f"f_{key}"]) and np.array_equal(t, g[f"t_{key}"])
-    assert cwt.dtype == (np.complex128 if dtype == np.float64 else np.complex64)
+    assert cwt.dtype == np.complex128  # as the reference returns it, whatever the record's dtype (styx_cwt.py:195-198)
     assert relmax(cwt, g[f"cwt_norm_{key}"]) <= tol["coef"]
     f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
-    assert np.array_equal(f2, f) and np.array_equal(t2, t)
+    assert np.array_equal(f2, f) and np.array_equal(t2, t) and stx.dtype == np.complex128  # styx_stx.py:228
     assert relmax(stx, g[f"stx_{key}"]) <= tol["coef"]
     c, bits, tc, fc = cwt_atoms.cwt_chirp_from_sig(sig, fs, order)
+    assert c.dtype == np.complex128 and bits.dtype == np.float64  # cwt_atoms.py:408,442
     assert np.array_equal(fc, g[f"chirp_f_{key}"]) and np.array_equal(tc, t)
     assert relmax(c, g[f"chirp_cwt_{key}"]) <= tol["coef"]
     check_bits(bits, g[f"chirp_cwt_{key}"], tol)
@@ -115,6 +119,35 @@ def test_stft_2d_batch_and_errors(golden):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_corner_cases_vs_reference(golden, dtype):
+    """Gaussian-window STFT (styx_fft.py:190-227), chirped atoms index_shift = +-1 (cwt_atoms.py:202-211) and the
+    unit-amplitude dictionary (styx_cwt.py:139) against the reference's own outputs."""
+    g = golden("corners_n2048.npz")
+    tol = TOL[dtype]
+    tag = np.dtype(dtype).name
+    sig = g[f"sig_{tag}"]
+    f, t, z = styx_fft.gtx_complex_pow2(sig, 1000.0, 256)
+    assert np.array_equal(f, g[f"gtx_f_{tag}"]) and np.array_equal(t, g[f"gtx_t_{tag}"]) and z.dtype == g[f"gtx_z_{tag}"].dtype
+    assert relmax(z, g[f"gtx_z_{tag}"]) <= tol["coef"]
+    f, t, z = styx_fft.gtx_complex_pow2(sig, 1000.0, 200, gaussian_sigma=30, overlap_points=150, nfft_points=512)
+    assert np.array_equal(t, g[f"gtx2_t_{tag}"]) and relmax(z, g[f"gtx2_z_{tag}"]) <= tol["coef"]
+    x = g["sig_float64"].astype(dtype)
+    for shift, key in ((1.0, "p1"), (-1.0, "m1")):
+        c, bits, _, fc = cwt_atoms.cwt_chirp_from_sig(x, 1000.0, 3, index_shift=shift)
+        assert np.array_equal(fc, g[f"shift_f_{key}"])
+        assert np.array_equal(np.array(cwt_atoms.chirp_mqg_from_n(3, shift)), g[f"shift_mqg_{key}"])
+        assert relmax(c, g[f"shift_cwt_{key}"]) <= tol["coef"], key
+        if shift > 0:
+            check_bits(bits, g[f"shift_cwt_{key}"], tol)
+    c6 = cwt_atoms.cwt_chirp_from_sig(x, 1000.0, 6, index_shift=1.0, dictionary_type="spect")[0]
+    assert relmax(c6[::3], g["shift_cwt_o6_spect_p1"]) <= tol["coef"]
+    f, _, unit = styx_cwt.cwt_complex_any_scale_pow2(3, x, 1000.0, dictionary_type="unit")
+    assert np.array_equal(f, g["unit_f_o3"]) and relmax(unit, g["unit_cwt_o3"]) <= tol["coef"]
+    atoms, _, _, _, amp = styx_cwt.wavelet_centered_4cwt(3, len(x), f[:4], 1000.0, "unit")
+    assert relmax(atoms, g["unit_atoms"]) <= 1e-12 and np.array_equal(amp[:, 0], g["unit_amp"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tfr_info_vs_reference(golden, dtype):
     g = golden("small_n1024.npz")
     tol = TOL[dtype]
@@ -147,24 +180,40 @@ def _plan_with_all(n, fs, order, dtype, channels=1, workspace=None):
     return plan
 
 
-def check_digest(res, g, prefix, order, tol, rows):
-    coef = res.coef[0].cpu().numpy()
+def check_digest(res, g, prefix, order, tol, rows, channel=0):
+    """One record's result against a reference digest: sampled (or whole) panel rows, per-band and per-time power,
+    maximum, total and entropy."""
     tsel = g[f"{prefix}_tsel_o{order}"]
     ref_rows = g[f"{prefix}_rows_o{order}"]
-    got = coef[rows][:, tsel] if ref_rows.shape[1] != coef.shape[1] else coef[rows]
+    panel = res.coef[channel]
+    n_b, n = panel.shape
+    sel = panel[torch.from_numpy(np.asarray(rows)).to(panel.device)]
+    if ref_rows.shape[1] != n:
+        sel = sel[:, torch.from_numpy(tsel).to(panel.device)]
+    got = sel.cpu().numpy()
     scale = np.sqrt(float(g[f"{prefix}_pmax_o{order}"]))
     assert np.max(np.abs(got - ref_rows)) / scale <= tol["coef"]
-    pb = res.power_band[0].cpu().numpy()
+    if "row" in tol and len(rows) == n_b:  # every band kept: each is held to its own maximum
+        rel_row = np.max(np.abs(got - ref_rows), axis=1) / np.max(np.abs(ref_rows), axis=1)
+        assert rel_row.max() <= tol["row"], (prefix, int(np.argmax(rel_row)), float(rel_row.max()))
+    if res.bits is not None:
+        bsel = res.bits[channel][torch.from_numpy(np.asarray(rows)).to(panel.device)]
+        if ref_rows.shape[1] != n:
+            bsel = bsel[:, torch.from_numpy(tsel).to(panel.device)]
+        check_bits(bsel.cpu().numpy(), ref_rows, tol)
+    pb = res.power_band[channel].cpu().numpy()
     ref_pb = g[f"{prefix}_psum_band_o{order}"]
     assert np.max(np.abs(pb - ref_pb)) / ref_pb.max() <= tol["red"]
-    pt = res.power_time[0].cpu().numpy().astype(np.float64)
+    if "row" in tol and len(rows) == n_b:
+        assert np.max(np.abs(pb - ref_pb) / ref_pb) <= 10 * tol["red"]  # every band's own power, weak bands included
+    pt = res.power_time[channel].cpu().numpy().astype(np.float64)
     ref_pt = g[f"{prefix}_psum_time_o{order}"]
     pt = pt[tsel] if ref_pt.shape[0] != pt.shape[0] else pt
     assert np.max(np.abs(pt - ref_pt)) / ref_pt.max() <= tol["red"]
-    st = res.stats[0].cpu().numpy()
+    st = res.stats[channel].cpu().numpy()
     assert abs(st[0] - float(g[f"{prefix}_pmax_o{order}"])) / st[0] <= 10 * tol["coef"]
     assert abs(st[1] - float(g[f"{prefix}_ptot_o{order}"])) / st[1] <= tol["red"]
-    ent = float(res.entropy_bits[0])
+    ent = float(res.entropy_bits[channel])
     assert abs(ent - float(g[f"{prefix}_entropy_bits_o{order}"])) <= tol["red"] * 20
 
 
@@ -201,10 +250,27 @@ def test_benchmark_size_vs_reference_and_properties(golden):
     sig = torch.from_numpy(x).cuda().unsqueeze(0)
     plan = _plan_with_all(n, fs, order, np.float32)
     rows = g["rows_o3"]
-    res_c = plan.cwt(sig, coef=True, reductions=True)
+    assert len(rows) == len(plan.freq[0])  # the fixture holds every band: each sub-engine's rows are reference-pinned
+    res_c = plan.cwt(sig, coef=True, bits=True, reductions=True)
     check_digest(res_c, g, "cwt", order, tol, rows)
-    res_s = plan.stx(sig, coef=True, reductions=True)
+    res_c.bits = None
+    res_s = plan.stx(sig, coef=True, bits=True, reductions=True)
     check_digest(res_s, g, "stx", order, tol, rows)
+    res_s.bits = None
+    fus_c, fus_s = plan.cwt_stx(sig, coef=True, reductions=True)  # the benchmark's call: joint launches
+    check_digest(fus_c, g, "cwt", order, tol, rows)
+    check_digest(fus_s, g, "stx", order, tol, rows)
+    del fus_c, fus_s
+    # cwt_atoms (circular CWT, 49 bands) on the native engine, every band against the reference
+    c_atoms, bits_atoms, _, fc = cwt_atoms.cwt_chirp_from_sig(sig[0], fs, order)
+    assert np.array_equal(fc, g["chirp_f_o3"])
+    got = c_atoms[:, torch.from_numpy(g["chirp_tsel_o3"]).cuda()].cpu().numpy()
+    ref = g["chirp_rows_o3"]
+    assert np.max(np.abs(got - ref)) / np.sqrt(float(g["chirp_pmax_o3"])) <= tol["coef"]
+    rel_row = np.max(np.abs(got - ref), axis=1) / np.max(np.abs(ref), axis=1)
+    assert rel_row.max() <= tol["row"], ("chirp", int(np.argmax(rel_row)), float(rel_row.max()))
+    del c_atoms, bits_atoms
+    engine.clear_plans()
     # fused reductions agree with a direct reduction of the stored panel
     p = (res_s.coef[0].abs() ** 2).double()
     assert torch.allclose(p.sum(dim=1), res_s.power_band[0], rtol=1e-5)
@@ -222,6 +288,63 @@ def test_benchmark_size_vs_reference_and_properties(golden):
     shifted = plan.stx(torch.roll(sig, s, dims=1)).coef
     assert float((shifted.abs() - torch.roll(res_s.coef, s, dims=2).abs()).abs().max() / res_s.coef.abs().max()) <= 4 * tol["coef"]
     plan.close()
+
+
+def test_config3_64_channels_order12_vs_reference(golden):
+    """Config 3 of BASELINE.json (configs[2]): 64 channels x 2^20 samples, order 12 (167 bands), float32, the full
+    stack -- STFT + CWT + STX + entropy -- in one batch on one GPU.  Channel 0 is the record of the reference fixture
+    (every band of both panels at ~1250 sampled times, all reductions); every other channel's batch result is checked
+    against the same plan run on that record alone (sampled rows, all reductions); the STFT against the oracle."""
+    from quantum_inferno_amd import synth
+
+    g = golden("large_n1048576_o12.npz")
+    n, fs, order, n_ch = 1 << 20, 1000.0, 12, 64
+    tol = TOL[np.float32]
+    x = synth.channels(n, fs, 0, n_ch, n_ch, np.float32)
+    assert np.max(np.abs(x[0, :: n // 4096] - g["sig_samples"])) <= 1e-6  # channel 0 = the fixture's record
+    sig = torch.from_numpy(x).cuda()
+    plan = _plan_with_all(n, fs, order, np.float32, channels=n_ch)  # (8 GiB of scratch: the batch goes through in tiles)
+    assert np.array_equal(plan.freq[0], g["f_o12"]) and len(plan.freq[0]) == 167
+    rows = g["rows_o12"]
+    assert len(rows) == 167
+    res_c, res_s = plan.cwt_stx(sig, coef=True, reductions=True)
+    torch.cuda.synchronize()
+    assert res_c.coef.shape == (n_ch, 167, n) and res_s.coef.shape == (n_ch, 167, n)
+    check_digest(res_c, g, "cwt", order, tol, rows)
+    check_digest(res_s, g, "stx", order, tol, rows)
+    # every channel of the batch against its single-record run (other tiling, same kernels)
+    tsel = torch.from_numpy(g["cwt_tsel_o12"]).cuda()
+    one = None
+    for c in range(n_ch):
+        one = plan.cwt_stx(sig[c : c + 1], coef=True, reductions=True, out=one)
+        for batch, single in ((res_c, one[0]), (res_s, one[1])):
+            a, b = batch.coef[c][:, tsel], single.coef[0][:, tsel]
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), c
+            assert torch.allclose(batch.power_band[c], single.power_band[0], rtol=1e-5), c
+            assert torch.allclose(batch.power_time[c], single.power_time[0], rtol=1e-4, atol=1e-7 * float(single.power_time.max())), c
+            assert torch.allclose(batch.stats[c, :3], single.stats[0, :3], rtol=1e-5), c
+    del res_c, res_s, one
+    plan.close()
+    torch.cuda.empty_cache()
+    # cwt_atoms at order 12 (170 bands, circular) for the fixture's record
+    c_atoms, _, _, fc = cwt_atoms.cwt_chirp_from_sig(sig[0], fs, order)
+    assert np.array_equal(fc, g["chirp_f_o12"])
+    got = c_atoms[:, torch.from_numpy(g["chirp_tsel_o12"]).cuda()].cpu().numpy()
+    ref = g["chirp_rows_o12"]
+    assert np.max(np.abs(got - ref)) / np.sqrt(float(g["chirp_pmax_o12"])) <= tol["coef"]
+    del c_atoms
+    engine.clear_plans()
+    # the STFT of the stack: order 12 -> 2048-sample segments, (1025 x 1025) per channel
+    stft = styx_fft.StftPlan(n, n_ch, fs, order, torch.float32)
+    z, bits = stft.run(sig)
+    assert z.shape == (n_ch, 1025, 1025)
+    for c in (0, 17, 63):
+        ref_z, ref_bits, ref_t, ref_f = orc.stft_from_sig(x[c], fs, order)
+        assert np.array_equal(stft.time_s, ref_t) and np.array_equal(stft.frequency_hz, ref_f)
+        assert relmax(z[c].cpu().numpy(), ref_z) <= tol["coef"]
+        check_bits(bits[c].cpu().numpy(), ref_z, tol)
+    zw, bw, tw, fw = styx_fft.stft_from_sig(sig[5], fs, order)  # the reference-signature wrapper: the same kernels
+    assert float((zw - z[5]).abs().max()) <= 1e-6 * float(z[5].abs().max()) and np.array_equal(tw, stft.time_s)
 
 
 def test_batches_tiles_and_oracle_on_noise():

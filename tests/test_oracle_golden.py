@@ -215,3 +215,58 @@ def test_short_time_fft_wrappers(golden):
         assert relmax(o.stft(sig), g[f"S_{tag}"]) <= 1e-13
         ts, x = orc.istft_tukey(g[f"S_{tag}"], fs, alpha, seg, ov, scaling)
         assert np.array_equal(ts, g[f"ts_{tag}"]) and relmax(x, g[f"x_{tag}"]) <= 1e-12
+
+
+def test_corner_cases_vs_reference(golden):
+    """Gaussian-window STFT, chirped atoms (index_shift = +-1) and the unit-amplitude dictionary against the
+    reference's own outputs (tests/golden/corners_n2048.npz)."""
+    g = golden("corners_n2048.npz")
+    for tag in ("float64", "float32"):
+        sig = g[f"sig_{tag}"]
+        f, t, z = orc.gtx_complex_pow2(sig, 1000.0, 256)
+        assert np.array_equal(f, g[f"gtx_f_{tag}"]) and np.array_equal(t, g[f"gtx_t_{tag}"])
+        assert z.dtype == g[f"gtx_z_{tag}"].dtype and np.array_equal(z, g[f"gtx_z_{tag}"])
+        f, t, z = orc.gtx_complex_pow2(sig, 1000.0, 200, sigma=30, overlap=150, nfft=512)
+        assert np.array_equal(t, g[f"gtx2_t_{tag}"]) and np.array_equal(z, g[f"gtx2_z_{tag}"])
+    sig = g["sig_float64"]
+    for shift, tag in ((1.0, "p1"), (-1.0, "m1")):
+        c, bits, _, fc = orc.cwt_chirp_fft(sig, 1000.0, 3, index_shift=shift)
+        assert np.array_equal(fc, g[f"shift_f_{tag}"])
+        assert np.array_equal(np.array(orc.chirp_mqg_from_n(3, shift)), g[f"shift_mqg_{tag}"])
+        assert relmax(c, g[f"shift_cwt_{tag}"]) < 1e-11
+    assert np.max(np.abs(orc.cwt_chirp_fft(sig, 1000.0, 3, index_shift=1.0)[1] - g["shift_bits_p1"])) < 1e-9
+    c6 = orc.cwt_chirp_fft(sig, 1000.0, 6, index_shift=1.0, dict_type="spect")[0]
+    assert relmax(c6[::3], g["shift_cwt_o6_spect_p1"]) < 1e-11
+    f, _, unit = orc.cwt_fft(3, sig, 1000.0, "unit")
+    assert np.array_equal(f, g["unit_f_o3"]) and relmax(unit, g["unit_cwt_o3"]) < 1e-14
+    atoms = np.stack([orc.gabor_atom_row(3, len(sig), fj, 1000.0, "unit") for fj in f[:4]])
+    assert relmax(atoms, g["unit_atoms"]) < 1e-15 and np.array_equal(g["unit_amp"], np.ones(4))
+
+
+@pytest.mark.parametrize("order,name", [(3, "large_n1048576.npz"), (12, "large_n1048576_o12.npz")])
+def test_benchmark_length_rows(golden, order, name):
+    """The oracle at the benchmark length (2^20 samples, float32 record) against the reference, band by band for a
+    sample of bands of every kind the GPU engines treat differently (lowest = atoms longer than the record, narrow
+    spectra, short atoms up to the highest band), at the fixture's ~1250 sampled times; cwt_atoms likewise."""
+    g = golden(name)
+    n, fs = 1 << 20, 1000.0
+    sig = orc.synth_chirp(n, fs, dtype=np.float32)
+    assert np.array_equal(sig[:: n // 4096], g["sig_samples"])
+    n_b = len(g[f"f_o{order}"])
+    pick = sorted({0, 1, n_b // 5, n_b // 2, (3 * n_b) // 4, n_b - 2, n_b - 1})
+    tsel = g[f"cwt_tsel_o{order}"]
+    f, _, cwt = orc.cwt_fft(order, sig, fs, bands=pick)
+    assert np.array_equal(f, g[f"f_o{order}"])
+    ref = g[f"cwt_rows_o{order}"][pick]
+    assert np.max(np.abs(cwt[:, tsel] - ref)) <= 1e-12 * np.abs(ref).max()
+    assert np.allclose((np.abs(cwt) ** 2).sum(axis=1), g[f"cwt_psum_band_o{order}"][pick], rtol=1e-11)
+    _, _, stx = orc.stx_fft(order, sig, fs, bands=pick)
+    ref = g[f"stx_rows_o{order}"][pick]
+    assert np.max(np.abs(stx[:, tsel] - ref)) <= 1e-12 * np.abs(ref).max()
+    assert np.allclose((np.abs(stx) ** 2).sum(axis=1), g[f"stx_psum_band_o{order}"][pick], rtol=1e-11)
+    n_c = len(g[f"chirp_f_o{order}"])
+    pick_c = [0, n_c // 2, n_c - 1]
+    c, _, _, fc = orc.cwt_chirp_fft(sig, fs, order, bands=pick_c)
+    assert np.array_equal(fc, g[f"chirp_f_o{order}"])
+    ref = g[f"chirp_rows_o{order}"][pick_c]
+    assert np.max(np.abs(c[:, tsel] - ref)) <= 1e-9 * np.abs(ref).max()
