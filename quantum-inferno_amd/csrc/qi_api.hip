@@ -303,16 +303,22 @@ struct qi_plan {
     void* bank = nullptr;  // [rows][kBlk] complex filter spectra
     int32_t rows = 0;
     native::BlockBand* d_bands = nullptr;  // all reach groups, group by group
-    native::BlockItem* d_items = nullptr;  // one per workgroup, most expensive first
-    int32_t nitems = 0, nplanes = 0;
-    int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
+    // Work items (one per workgroup, most expensive first) in two cuts: [0] few bands per workgroup -- many workgroups,
+    // for calls with one or two records --, [1] many bands per workgroup -- fewer forward transforms of the same block
+    // and fewer per-time planes, for batches that fill the chip anyway.
+    struct ItemList {
+      native::BlockItem* d_items = nullptr;
+      int32_t nitems = 0, nplanes = 0;
+      int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
+      std::vector<native::BlockItem> h_items;  // host copy of d_items (the joint launch list is made from it)
+    } var[2];
     int64_t max_blocks = 0;  // partial slots a band row needs
     std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
-    std::vector<native::BlockItem> h_items;             // host copy of d_items (the joint launch list is made from it)
     void release() {
       if (bank) (void)hipFree(bank);
       if (d_bands) (void)hipFree(d_bands);
-      if (d_items) (void)hipFree(d_items);
+      for (auto& v : var)
+        if (v.d_items) (void)hipFree(v.d_items);
       *this = BlockTable();
     }
   } blk[3];
@@ -331,6 +337,12 @@ struct qi_plan {
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
   // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
   int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
+  int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
+                           // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
+                           // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
+  int native_gather_fused = 4;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
+                                // (no gather launch, two passes over the coarse storage fewer: -30 % of that stage at 16 records);
+                                // below it the gather launch's 16 x more workgroups win (one record: 28 vs 43 us); 0: never
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // split bands of the styx bank (atoms longer than the record): zoom engine + edge pieces, see split_taper
@@ -342,16 +354,19 @@ struct qi_plan {
   int32_t nsplit = 0;
   int native_blk_analytic = 1; // evaluate Gaussian filter spectra in registers instead of reading their table rows
   FusedCarry carry;
-  native::DualItem* d_dual = nullptr;  // joint block launch of qi_cwt_stx (styx + Stockwell tables), built on first use
-  int32_t n_dual = 0;
-  bool dual_valid = false;
+  native::DualItem* d_dual[2] = {nullptr, nullptr};  // joint block launch of qi_cwt_stx (styx + Stockwell tables) per item cut, built on first use
+  int32_t n_dual[2] = {0, 0};
+  bool dual_valid[2] = {false, false};
   int native_fuse = 4;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
                                // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
+  int native_blk_half = 1;     // block bands whose filter spectrum lies in the lower half of the block spectrum: eight weights, pruned first pass
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int64_t native_tile = 0;     // qi_cwt_stx: at most this many records per joint tile (0: as many as the scratch holds)
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
+  int native_blk_bands_batch = 12;  // the same for batches of native_blk_batch_from records or more (item cut 1)
+  int native_blk_batch_from = 4;
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
   int64_t edge_wmax = 0;
@@ -704,7 +719,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
                        hipStream_t st) {
   auto& bt = p->blk[kind];
   bt.release();
-  p->dual_valid = false;
+  p->dual_valid[0] = p->dual_valid[1] = false;
   if (picks.empty()) return QI_OK;
   const int32_t rows = (int32_t)picks.size();
   QI_TRY(fft_c2c<double>(p->fft, taps, native::kBlk, rows, HIPFFT_FORWARD, st));
@@ -716,7 +731,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   bt.demod = demod;
   const int wqs[3] = {1, 2, 4};
   std::vector<native::BlockBand> list;
-  std::vector<native::BlockItem> items;
+  int32_t group_first[3] = {0, 0, 0}, group_count[3] = {0, 0, 0};
   for (int g = 0; g < 3; ++g) {
     const int32_t first = (int32_t)list.size();
     for (int32_t r = 0; r < rows; ++r) {
@@ -741,6 +756,9 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
         b.rot_a[1] = (float)std::sin(2.0 * M_PI * ba / 16.0);
         b.rot_b[0] = (float)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
         b.rot_b[1] = (float)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+      } else if (b.analytic && p->native_blk_half && picks[r].kappa - half - 1.0 >= 0.0 &&
+                 picks[r].kappa + half + 1.0 < (double)(native::kBlk / 2)) {
+        b.narrow = 2;  // every weight above 2^-30 of the peak lies in the lower half of the block spectrum
       }
       for (int k = 0; k < 4; ++k) {
         // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
@@ -751,58 +769,73 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       }
       list.push_back(b);
     }
-    const int32_t count = (int32_t)list.size() - first;
-    if (count == 0) continue;
-    // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
-    const int32_t nchunk = (int32_t)ceil_div(count, p->native_blk_bands);
+    group_first[g] = first;
+    group_count[g] = (int32_t)list.size() - first;
+    if (group_count[g] == 0) continue;
     const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
     if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
-    if (getenv("QI_NATIVE_VERBOSE"))
-      fprintf(stderr, "[qi plan] block table %d, reach <= %d: %d bands (%d analytic, %d narrow) in %d workgroups x %lld blocks\n", kind,
-              256 * wqs[g], count,
-              (int)std::count_if(list.begin() + first, list.end(), [](const native::BlockBand& b) { return b.analytic != 0; }),
-              (int)std::count_if(list.begin() + first, list.end(), [](const native::BlockBand& b) { return b.narrow != 0; }),
-              nchunk, (long long)nblocks);
     for (int32_t q = first; q < (int32_t)list.size(); ++q) bt.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
-    for (int32_t c = 0; c < nchunk; ++c) {
-      const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
-      const int32_t hi = first + (int32_t)((int64_t)count * (c + 1) / nchunk);
-      for (int64_t b = 0; b < nblocks; ++b) {
-        native::BlockItem it;
-        it.wq = wqs[g];
-        it.block = (int32_t)b;
-        it.band_first = lo;
-        it.band_count = hi - lo;
-        it.plane = bt.nplanes;
-        it.stat_slot = 0;
-        items.push_back(it);
-      }
-      bt.nplanes += 1;
-    }
   }
-  std::stable_sort(items.begin(), items.end(),
-                   [](const native::BlockItem& x, const native::BlockItem& y) { return x.band_count > y.band_count; });
-  for (size_t i = 0; i < items.size(); ++i) items[i].stat_slot = (int32_t)i;
-  bt.nitems = (int32_t)items.size();
+  int64_t split_blocks = 0;
   if (kind == 0 && p->nsplit > 0) {
-    // the edge items of the split bands ride at the end of the launch (light items: they fill its tail); each split
-    // band has a per-time plane and one partial slot per block like the other bands of the launch
-    const int wq = (int)(p->native_split_e / 512);
-    const int64_t nblocks = ceil_div(p->n, native::block_valid(wq));
-    if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
-    for (int32_t sb = 0; sb < p->nsplit; ++sb) {
-      for (int64_t b = 0; b < nblocks; ++b)
-        items.push_back({-wq, (int32_t)b, sb, 0, bt.nplanes, (int32_t)items.size()});
-      bt.nplanes += 1;
-      bt.h_bands.push_back({p->h_split_bands[sb], (int32_t)nblocks});
+    split_blocks = ceil_div(p->n, native::block_valid((int)(p->native_split_e / 512)));
+    if (split_blocks > bt.max_blocks) bt.max_blocks = split_blocks;
+    for (int32_t sb = 0; sb < p->nsplit; ++sb) bt.h_bands.push_back({p->h_split_bands[sb], (int32_t)split_blocks});
+  }
+  for (int v = 0; v < 2; ++v) {
+    auto& il = bt.var[v];
+    const int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
+    std::vector<native::BlockItem> items;
+    for (int g = 0; g < 3; ++g) {
+      const int32_t first = group_first[g], count = group_count[g];
+      if (count == 0) continue;
+      // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
+      const int32_t nchunk = (int32_t)ceil_div(count, per_wg);
+      const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
+      if (getenv("QI_NATIVE_VERBOSE"))
+        fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
+                256 * wqs[g], count,
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.analytic != 0; }),
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 1; }),
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 2; }),
+                nchunk, (long long)nblocks);
+      for (int32_t c = 0; c < nchunk; ++c) {
+        const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
+        const int32_t hi = first + (int32_t)((int64_t)count * (c + 1) / nchunk);
+        for (int64_t b = 0; b < nblocks; ++b) {
+          native::BlockItem it;
+          it.wq = wqs[g];
+          it.block = (int32_t)b;
+          it.band_first = lo;
+          it.band_count = hi - lo;
+          it.plane = il.nplanes;
+          it.stat_slot = 0;
+          items.push_back(it);
+        }
+        il.nplanes += 1;
+      }
     }
-    bt.nedge_items = (int32_t)items.size() - bt.nitems;
+    std::stable_sort(items.begin(), items.end(),
+                     [](const native::BlockItem& x, const native::BlockItem& y) { return x.band_count > y.band_count; });
+    for (size_t i = 0; i < items.size(); ++i) items[i].stat_slot = (int32_t)i;
+    il.nitems = (int32_t)items.size();
+    if (kind == 0 && p->nsplit > 0) {
+      // the edge items of the split bands ride at the end of the launch (light items: they fill its tail); each split
+      // band has a per-time plane and one partial slot per block like the other bands of the launch
+      const int wq = (int)(p->native_split_e / 512);
+      for (int32_t sb = 0; sb < p->nsplit; ++sb) {
+        for (int64_t b = 0; b < split_blocks; ++b)
+          items.push_back({-wq, (int32_t)b, sb, 0, il.nplanes, (int32_t)items.size()});
+        il.nplanes += 1;
+      }
+      il.nedge_items = (int32_t)items.size() - il.nitems;
+    }
+    il.h_items = items;
+    QI_HIP(hipMalloc((void**)&il.d_items, items.size() * sizeof(native::BlockItem)));
+    QI_HIP(hipMemcpy(il.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
   }
   QI_HIP(hipMalloc((void**)&bt.d_bands, list.size() * sizeof(native::BlockBand)));
   QI_HIP(hipMemcpy(bt.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
-  bt.h_items = items;
-  QI_HIP(hipMalloc((void**)&bt.d_items, items.size() * sizeof(native::BlockItem)));
-  QI_HIP(hipMemcpy(bt.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
   QI_HIP(hipStreamSynchronize(st));
   bt.ready = true;
   return QI_OK;
@@ -1086,18 +1119,18 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
 // Work items of the joint block launch: the items of the styx table (0) and of the Stockwell table (2) on the same
 // (reach group, block) are paired chunk by chunk -- one forward transform serves both; what has no partner stays single;
 // the edge items of the styx table keep their place at the end.
-int build_dual_items(qi_plan* p) {
-  if (p->dual_valid) return QI_OK;
-  if (p->d_dual) (void)hipFree(p->d_dual);
-  p->d_dual = nullptr;
-  p->n_dual = 0;
+int build_dual_items(qi_plan* p, int cut) {
+  if (p->dual_valid[cut]) return QI_OK;
+  if (p->d_dual[cut]) (void)hipFree(p->d_dual[cut]);
+  p->d_dual[cut] = nullptr;
+  p->n_dual[cut] = 0;
   std::map<std::pair<int32_t, int32_t>, std::pair<std::vector<native::BlockItem>, std::vector<native::BlockItem>>> at;
   std::vector<native::DualItem> dual, edge;
-  for (const auto& it : p->blk[0].h_items) {
+  for (const auto& it : p->blk[0].var[cut].h_items) {
     if (it.wq < 0) edge.push_back({it.wq, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, 0, 0, 0, 0});
     else at[{it.wq, it.block}].first.push_back(it);
   }
-  for (const auto& it : p->blk[2].h_items) at[{it.wq, it.block}].second.push_back(it);
+  for (const auto& it : p->blk[2].var[cut].h_items) at[{it.wq, it.block}].second.push_back(it);
   for (const auto& kv : at) {
     const auto& a = kv.second.first;
     const auto& b = kv.second.second;
@@ -1123,10 +1156,10 @@ int build_dual_items(qi_plan* p) {
   });
   dual.insert(dual.end(), edge.begin(), edge.end());
   if (dual.empty()) return QI_OK;
-  QI_HIP(hipMalloc((void**)&p->d_dual, dual.size() * sizeof(native::DualItem)));
-  QI_HIP(hipMemcpy(p->d_dual, dual.data(), dual.size() * sizeof(native::DualItem), hipMemcpyHostToDevice));
-  p->n_dual = (int32_t)dual.size();
-  p->dual_valid = true;
+  QI_HIP(hipMalloc((void**)&p->d_dual[cut], dual.size() * sizeof(native::DualItem)));
+  QI_HIP(hipMemcpy(p->d_dual[cut], dual.data(), dual.size() * sizeof(native::DualItem), hipMemcpyHostToDevice));
+  p->n_dual[cut] = (int32_t)dual.size();
+  p->dual_valid[cut] = true;
   return QI_OK;
 }
 
@@ -1137,8 +1170,12 @@ int launch_tail_call(const TailCall& t, hipStream_t st) {
 
 int launch_zoom_all(qi_plan* p, const native::ZoomArgs<float>& z, int64_t ct, hipStream_t st) {
   p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-  QI_TRY(native::launch_zoom_gather<float>(z, 0, ct, st));
-  QI_TRY(native::launch_zoom_coarse<float>(z, 0, ct, st));
+  if (p->native_gather_fused > 0 && ct >= p->native_gather_fused) {
+    QI_TRY(native::launch_zoom_coarse_gather<float>(z, ct, st));
+  } else {
+    QI_TRY(native::launch_zoom_gather<float>(z, 0, ct, st));
+    QI_TRY(native::launch_zoom_coarse<float>(z, 0, ct, st));
+  }
   p->prof.end(QI_STAGE_ZOOM_COARSE, st);
   p->prof.begin(st, QI_STAGE_ZOOM);
   QI_TRY(native::launch_zoom<float>(z, ct, st));
@@ -1203,11 +1240,13 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // block engine launches (one per reach group): their chunks come after the pass-2 chunks
   const auto& bt = p->blk[kind];
   const bool blocks = kind != 1 && bt.ready;
+  const int cut = C >= p->native_blk_batch_from ? 1 : 0;  // (both halves of a joint tile see the same C)
+  const auto& il = bt.var[cut];
   const int chunk_p2 = chunk_total;
   int64_t blk_stats = 0, blk_slots = 0;
   if (blocks) {
-    chunk_total += bt.nplanes;
-    blk_stats = bt.nitems + bt.nedge_items;
+    chunk_total += il.nplanes;
+    blk_stats = il.nitems + il.nedge_items;
     blk_slots = bt.max_blocks;
   }
   // zoom engine launch (narrow bands of the main table): its chunks come last
@@ -1379,17 +1418,29 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   }
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
-    auto launch_blocks = [&](hipStream_t bs) -> int {
+    // qi_cwt_stx, joint block launch: its band items need nothing but the records, so they run on a side stream BESIDE
+    // the zoom engine's launches (neither kernel fills the vector pipes by itself: ~47 % issue each); the edge items of the
+    // split bands follow the interpolation launch, whose output they add to
+    const bool joint_blk = finishing && blocks && p->native_fuse > 1 && finish->ct == ct && !finish->demod && bt.demod &&
+                           (finish->blk.coef != nullptr) == (out->coef != nullptr) &&
+                           (finish->blk.bits != nullptr) == (out->bits != nullptr);
+    const bool pair = joint_blk && p->native_pair && !overlap;
+    if (pair && !p->side) {
+      QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+      QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+      QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
+    auto launch_blocks = [&](hipStream_t bs, int phase = 0) -> int {  // phase 1: band items only, 2: edge items only (joint launch)
       native::BlockArgs<T> b{};
       b.n = n;
-      b.nitems = bt.nitems;
-      b.nedge_items = bt.nedge_items;
+      b.nitems = il.nitems;
+      b.nedge_items = il.nedge_items;
       b.nsplit = nsplit;
       b.edge_band = p->d_split_bands;
       b.edge_bank = static_cast<const cplx<T>*>(p->split_bank);
       b.edge_part = zadd;
       b.panel_bands = (int32_t)B;
-      b.items = bt.d_items;
+      b.items = il.d_items;
       b.bands = bt.d_bands;
       b.bank = static_cast<const cplx<T>*>(bt.bank);
       b.sig = sig + c0 * n;
@@ -1416,11 +1467,17 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       }
       p->prof.unchain_span();
       p->prof.begin(bs, QI_STAGE_BLOCK);
-      const bool joint = finishing && p->native_fuse > 1 && finish->ct == ct && !finish->demod && bt.demod &&
-                         (finish->blk.coef != nullptr) == (b.coef != nullptr) && (finish->blk.bits != nullptr) == (b.bits != nullptr);
-      if (joint) {
-        QI_TRY(build_dual_items(p));
-        QI_TRY(native::launch_block_dual<T>(finish->blk, b, p->d_dual, p->n_dual, ct, bs));
+      if (joint_blk) {
+        QI_TRY(build_dual_items(p, cut));
+        const int32_t n_edge = p->blk[0].var[cut].nedge_items;
+        const native::DualItem* items = p->d_dual[cut];
+        int32_t count = p->n_dual[cut];
+        if (phase == 1) count -= n_edge;
+        if (phase == 2) {
+          items += count - n_edge;
+          count = n_edge;
+        }
+        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, ct, bs));
       } else {
         if (finishing) QI_TRY(native::launch_block<T>(finish->blk, finish->demod, finish->ct, bs));
         QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
@@ -1430,6 +1487,12 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       return QI_OK;
     };
     if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
+    if (pair) {
+      QI_HIP(hipEventRecord(p->ev_fork, st));
+      QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      QI_TRY(launch_blocks(p->side, 1));
+      QI_HIP(hipEventRecord(p->ev_join, p->side));
+    }
     if (overlap) {  // fork: the block launch follows the clearing of the partials and nothing else
       QI_HIP(hipEventRecord(p->ev_fork, st));
       QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
@@ -1559,9 +1622,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       } else {
         const bool joint = finishing && finish->has_zoom && finish->ct == ct;
         p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-        if (joint) {
+        const bool gfused = p->native_gather_fused > 0 && ct >= p->native_gather_fused;
+        if (joint && gfused) {
+          QI_TRY(native::launch_zoom_coarse_gather2<T>(finish->zoom, z, ct, st));
+        } else if (joint) {
           QI_TRY(native::launch_zoom_gather2<T>(finish->zoom, z, ct, st));
           QI_TRY(native::launch_zoom_coarse2<T>(finish->zoom, z, ct, st));
+        } else if (gfused) {
+          QI_TRY(native::launch_zoom_coarse_gather<T>(z, ct, st));
         } else {
           QI_TRY(native::launch_zoom_gather<T>(z, zt.zoom_max_level, ct, st));
           QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
@@ -1585,7 +1653,12 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       finish->has_zoom = false;
     }
     // (the edge items of the block launch finish the split bands the zoom launch began: it comes after it)
-    if (blocks && !overlap) QI_TRY(launch_blocks(st));
+    if (pair) {
+      QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+      if (p->blk[0].var[cut].nedge_items > 0) QI_TRY(launch_blocks(st, 2));
+    } else if (blocks && !overlap) {
+      QI_TRY(launch_blocks(st));
+    }
     if (overlap) QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));  // join before the reductions are finalised
     p->prof.begin(st, QI_STAGE_EPILOGUE);
     if (shorts) {
@@ -1687,6 +1760,11 @@ int stft_impl(int device, const void* sig, int64_t C, int64_t n, const void* win
                      int64_t nfft, double scale, void* Z, void* bits, double eps, char* scratch, hipStream_t st) {
   const int64_t nseg = qi_stft_segments(n, seg, hop);
   const int64_t nf = nfft / 2 + 1;
+  static const bool fused_off = getenv("QI_STFT_FUSED") && atoi(getenv("QI_STFT_FUSED")) == 0;
+  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft))  // one kernel: segments, transform and store from LDS
+    return launch_stft_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<cplx<T>*>(Z),
+                                static_cast<T*>(bits), C, n, seg, hop, nfft, nseg, seg / 2, scale,
+                                eps == 0.0 ? 2.220446049250313e-16 : eps, st);
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
@@ -1830,6 +1908,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
   if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
   if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_PAIR")) p->native_pair = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_GATHER_FUSED")) p->native_gather_fused = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
   if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
   if (const char* e = getenv("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
@@ -1838,6 +1918,9 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_TILE")) p->native_tile = atoll(e);
   if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
   if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
+  if (const char* e = getenv("QI_NATIVE_BLK_BANDS_BATCH")) p->native_blk_bands_batch = atoi(e) > 0 ? atoi(e) : p->native_blk_bands_batch;
+  if (const char* e = getenv("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
+  if (const char* e = getenv("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -1909,7 +1992,8 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->d_edge) (void)hipFree(p->d_edge);
   if (p->split_bank) (void)hipFree(p->split_bank);
   if (p->d_split_bands) (void)hipFree(p->d_split_bands);
-  if (p->d_dual) (void)hipFree(p->d_dual);
+  for (auto* d : p->d_dual)
+    if (d) (void)hipFree(d);
   for (int b = 0; b < 2; ++b)
     if (p->bank[b]) (void)hipFree(p->bank[b]);
   if (p->d_stx_idx) (void)hipFree(p->d_stx_idx);

@@ -18,6 +18,7 @@
 #include "qi_device.hpp"
 #include "qi_native.hpp"
 #include "qi_fft_reg.hpp"
+#include "qi_zoom_gather.hpp"
 
 namespace qi {
 namespace native {
@@ -259,7 +260,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     const BlockBand bd = bd_next;
     if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
     cplx<T> v[16];
-    if (bd.narrow) {
+    if (bd.narrow == 1) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
       // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
       QI_BSTAMP(1);
@@ -287,18 +288,39 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       // panel costs HBM bandwidth)
       QI_BSTAMP(1);
       QI_BSTAMP(2);
+      // (narrow = 2: every weight above 2^-30 of the peak belongs to a bin below kBlk / 2 -- no wrap-around among the
+      // lower eight values of a thread, and the upper eight are taken as zero)
+      const bool lower = bd.narrow == 2;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
+      for (int b = 0; b < 8; ++b) {
         T dk = (T)(col + 256 * b - bd.kappa_int) - (T)bd.kappa_frac;
         T amp = (T)bd.amp;
-        if (dk > (T)(kBlk / 2)) {
+        if (!lower && dk > (T)(kBlk / 2)) {
           dk -= (T)kBlk;
           if (!DEMOD) amp = -amp;  // half-integer sample grid: the aliases alternate in sign
         }
-        if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
+        if (DEMOD && !lower && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
         const T e = (T)bd.cw * dk;
         const T r = amp * fast_exp2(-e * e);
         v[b] = mk<T>(S[b].x * r, S[b].y * r);
+      }
+      if (lower) {
+#pragma unroll
+        for (int b = 8; b < 16; ++b) v[b] = mk<T>(T(0), T(0));
+      } else {
+#pragma unroll
+        for (int b = 8; b < 16; ++b) {
+          T dk = (T)(col + 256 * b - bd.kappa_int) - (T)bd.kappa_frac;
+          T amp = (T)bd.amp;
+          if (dk > (T)(kBlk / 2)) {
+            dk -= (T)kBlk;
+            if (!DEMOD) amp = -amp;
+          }
+          if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
+          const T e = (T)bd.cw * dk;
+          const T r = amp * fast_exp2(-e * e);
+          v[b] = mk<T>(S[b].x * r, S[b].y * r);
+        }
       }
     } else {
       const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + col;
@@ -313,7 +335,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    if (!bd.narrow && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    if (bd.narrow != 1 && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
     QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;
@@ -670,6 +692,50 @@ __device__ __forceinline__ void zoom_coarse_plane(cplx<T>* __restrict__ plane0) 
 #pragma unroll
   for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
 }
+// The same with the gather step inside: the plane's 4096 inputs are formed in registers (zoom_gather_value) instead of
+// being written by a gather launch and read back -- one launch and two passes over the coarse storage fewer.
+template <typename T, bool STX>
+__device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, const uint32_t plane_i,
+                                                         cplx<T>* __restrict__ buf, cplx<T>* __restrict__ tw256) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
+  const BandDesc bd = a.bands[a.plane_band[plane_i]];
+  const uint32_t tau1 = plane_i - (uint32_t)bd.edge;
+  const int64_t ch = blockIdx.z;
+  const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);
+  cplx<T> v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = zoom_gather_value<T, STX>(a, bd, tau1, col + 256 * b, X);
+  {
+    float s, c;
+    sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+    tw256[tid] = mk<T>((T)c, (T)s);
+  }
+  cplx<T> w;
+  {
+    float s, c;
+    sincospif((float)col * (2.0f / 4096.0f), &s, &c);
+    w = mk<T>((T)c, (T)s);
+  }
+  fft4096<T, 1>(v, buf, tw256, w, tid, col);
+  cplx<T>* __restrict__ plane = a.coarse + ((int64_t)ch * a.planes + plane_i) * kBlk + col;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse2g(ZoomArgs<T> a0, ZoomArgs<T> a2) {
+  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> tw256[256];
+  if (blockIdx.x < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false>(a0, blockIdx.x, buf, tw256);
+  else zoom_coarse_plane_gather<T, true>(a2, blockIdx.x - (uint32_t)a0.planes, buf, tw256);
+}
+template <typename T, bool STX>
+__global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse_g(ZoomArgs<T> a) {
+  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> tw256[256];
+  zoom_coarse_plane_gather<T, STX>(a, blockIdx.x, buf, tw256);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse(ZoomArgs<T> a) {
   zoom_coarse_plane<T>(a.coarse + ((int64_t)blockIdx.z * a.planes + blockIdx.x) * kBlk);
@@ -831,6 +897,29 @@ int launch_zoom_coarse<float>(const ZoomArgs<float>& a, int max_level, int64_t n
   (void)max_level;
   dim3 grid((unsigned)a.planes, 1, (unsigned)n_channels);  // every plane of every band is one 4096-point transform
   k_zoom_coarse<float><<<grid, kBlkThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_zoom_coarse_gather<float>(const ZoomArgs<float>& a, int64_t n_channels, hipStream_t st) {
+  if (a.nbands <= 0) return QI_OK;
+  dim3 grid((unsigned)a.planes, 1, (unsigned)n_channels);
+  if (a.stx) k_zoom_coarse_g<float, true><<<grid, kBlkThreads, 0, st>>>(a);
+  else k_zoom_coarse_g<float, false><<<grid, kBlkThreads, 0, st>>>(a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <>
+int launch_zoom_coarse_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, int64_t n_channels,
+                                      hipStream_t st) {
+  if (a0.stx || !a2.stx || a0.nbands <= 0 || a2.nbands <= 0) {
+    set_error("zoom engine: the joint coarse stage takes a styx table and a Stockwell table");
+    return QI_ERR_STATE;
+  }
+  dim3 grid((unsigned)(a0.planes + a2.planes), 1, (unsigned)n_channels);
+  k_zoom_coarse2g<float><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

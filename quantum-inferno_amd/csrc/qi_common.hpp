@@ -150,6 +150,11 @@ int launch_finalize(const double* part_band, const double* part_stat, double* po
 template <typename T>
 int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
                        int64_t nfft, int64_t nseg, int64_t lead, hipStream_t st);
+// fused STFT (qi_stft_fused.hip): frames, transform and [frequency][time] store in one kernel
+bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft);
+template <typename T>
+int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st);
 template <typename T>
 int launch_welch_mean(const cplx<T>* F, T* pxx, int64_t C, int64_t nseg, int64_t nf, int64_t nfft, T scale2,
                       hipStream_t st);

@@ -98,6 +98,8 @@ struct BlockBand {
   // narrow = 1: the weights above 2^-30 of the peak lie within the 256 bins from `klo` (mod kBlk), so a thread holds at
   // most one non-zero value of the filtered spectrum and the first radix-16 pass of the inverse transform is a
   // product with powers of one phasor; rot_a / rot_b = exp(2 pi i b / 16) for b = klo / 256 and the next one
+  // narrow = 2: the weights above 2^-30 of the peak lie within bins (0, kBlk / 2): eight weights per thread and a first
+  // pass of the inverse transform without its first radix-2 stage
   int32_t narrow, klo;
   float rot_a[2], rot_b[2];
 };
@@ -220,6 +222,11 @@ template <typename T>
 int launch_zoom2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);  // and the interpolation
 template <typename T>
 int launch_zoom_coarse2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
+// gather and plane transforms in one launch (the inputs of a plane are formed in registers)
+template <typename T>
+int launch_zoom_coarse_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
+template <typename T>
+int launch_zoom_coarse_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 
 template <typename T>

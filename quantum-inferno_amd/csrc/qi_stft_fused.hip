@@ -1,0 +1,255 @@
+// Fused short-time Fourier transform (styx_fft.stft_complex_pow2 / stft_from_sig, ref styx_fft.py:14-57,152-187;
+// scipy.signal.stft with boundary="zeros", padded=True, detrend="constant", one-sided) for power-of-two transform
+// lengths up to 4096: ONE kernel instead of frames -> batched R2C FFT -> transpose.
+//
+// A workgroup owns G consecutive segments of one record.  Per segment a wave loads the (zero-extended) samples,
+// removes their mean (float64 sum, fixed order), applies the window and leaves the nfft real values in LDS packed as
+// M = nfft / 2 complex numbers z[m] = v[2m] + i v[2m+1]; the G transforms of M points run in place in LDS (radix-2^2
+// decimation in frequency, twiddles from an LDS table of exp(-2 pi i k / nfft) built once per workgroup, results in
+// bit-reversed order); the real-input spectra X[k], k = 0..M, are untangled from Z[k], Z[M - k] on the way out and
+// written [frequency][time]: the G segments of a bin are consecutive in memory, so every store is a run of G
+// coefficients (G = 16: 128 B).  HBM traffic = the record once (the 50 % overlap is served by the caches) + the
+// panel once (+ the bits panel when asked for): the algorithmic bytes of SURVEY s8(d).  No MFMA: an FFT has no dense
+// contraction.
+#include "qi_common.hpp"
+#include "qi_device.hpp"
+#include "qi_fft_reg.hpp"
+
+namespace qi {
+
+namespace {
+
+constexpr int kStftThreads = 256;
+
+template <typename T>
+__device__ __forceinline__ void sincospi_t(T x, T* s, T* c);
+template <>
+__device__ __forceinline__ void sincospi_t<float>(float x, float* s, float* c) {
+  sincospif(x, s, c);
+}
+template <>
+__device__ __forceinline__ void sincospi_t<double>(double x, double* s, double* c) {
+  sincospi(x, s, c);
+}
+
+template <typename T>
+__device__ __forceinline__ cplx<T> cadd(cplx<T> a, cplx<T> b) {
+  return mk<T>(a.x + b.x, a.y + b.y);
+}
+template <typename T>
+__device__ __forceinline__ cplx<T> csub(cplx<T> a, cplx<T> b) {
+  return mk<T>(a.x - b.x, a.y - b.y);
+}
+
+struct StftFusedArgs {
+  int64_t n, seg, hop, nseg, lead;  // lead: zero-extended samples in front of the record (seg / 2 for the STFT, 0 Welch)
+  int32_t log2g, G;                 // G = 1 << log2g segments per workgroup
+  double scale, eps;
+};
+
+// dynamic LDS: data [G][R (C + 1) + 1] complex | twiddles [M] complex (exp(-2 pi i k / (2 M)))
+//
+// The M-point transform of a segment is a four-step transform on the R x C matrix z[r][c] = z[c + C r] (rows padded
+// by one element, segments by one more: every access pattern below is free of bank conflicts):
+//   step 1: thread = column c: R-point transform over r in registers, times W_M^(c k1), back to row k1;
+//   step 2: thread = row k1:   C-point transform over c in registers: row k1, column k2 holds Z[k1 + R k2].
+template <typename T, int LOG2R, int LOG2C>
+__global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict__ sig, const T* __restrict__ win,
+                                                            cplx<T>* __restrict__ Z, T* __restrict__ bits,
+                                                            StftFusedArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  constexpr int R = 1 << LOG2R, C = 1 << LOG2C, M = R * C, RS = C + 1, TILE = R * RS + 1;
+  const int G = a.G;
+  cplx<T>* __restrict__ data = reinterpret_cast<cplx<T>*>(lds_raw);
+  cplx<T>* __restrict__ tw = data + (size_t)G * TILE;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int64_t c = blockIdx.y, m0 = (int64_t)blockIdx.x * G;
+  const T* __restrict__ x = sig + c * a.n;
+
+  for (int k = tid; k < M; k += kStftThreads) {
+    T s, co;
+    sincospi_t<T>((T)k / (T)M, &s, &co);  // exp(-i pi k / M)
+    tw[k] = mk<T>(co, -s);
+  }
+  // segments: one wave per segment (mean by wave shuffles, no workgroup barrier)
+  for (int g = wv; g < G; g += kStftThreads / kWave) {
+    const int64_t m = m0 + g;
+    cplx<T>* __restrict__ d = data + (size_t)g * TILE;
+    if (m >= a.nseg) {  // past the last segment: zeros (never stored)
+      for (int j = lane; j < M; j += kWave) d[(j >> LOG2C) * RS + (j & (C - 1))] = mk<T>(T(0), T(0));
+      continue;
+    }
+    // the segment's samples, once, into registers: lane l holds the pairs (2 j, 2 j + 1), j = l + 64 t (two coalesced
+    // loads per pair; out-of-record samples of the zero extension are zeros and count in the mean, as in the reference)
+    const int64_t base = m * a.hop - a.lead;
+    constexpr int NP = (M + kWave - 1) / kWave;
+    T v0[NP], v1[NP];
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const int64_t i0 = 2 * (int64_t)(lane + kWave * t), k0 = base + i0;
+      v0[t] = (i0 < a.seg && k0 >= 0 && k0 < a.n) ? x[k0] : T(0);
+      v1[t] = (i0 + 1 < a.seg && k0 + 1 >= 0 && k0 + 1 < a.n) ? x[k0 + 1] : T(0);
+      acc += (double)v0[t] + (double)v1[t];
+    }
+    acc = wave_sum(acc);
+    acc = __shfl(acc, 0, kWave);
+    const T mean = (T)(acc / (double)a.seg);
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const int j = lane + kWave * t;
+      const int64_t i0 = 2 * (int64_t)j;
+      const T w0 = i0 < a.seg ? win[i0] : T(0), w1 = i0 + 1 < a.seg ? win[i0 + 1] : T(0);
+      if (j < M) d[(j >> LOG2C) * RS + (j & (C - 1))] = mk<T>((v0[t] - mean) * w0, (v1[t] - mean) * w1);
+    }
+  }
+  __syncthreads();
+
+  // step 1: columns
+  for (int q = tid; q < G * C; q += kStftThreads) {
+    const int g = q >> LOG2C, cc = q & (C - 1);
+    cplx<T>* __restrict__ d = data + (size_t)g * TILE + cc;
+    cplx<T> v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = d[r * RS];
+    native::fft_reg<T, R, -1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) {
+      cplx<T> y = v[native::brev(k1, LOG2R)];
+      if (k1 > 0) {
+        const int j2 = 2 * cc * k1;  // W_M^(c k1) = exp(-i pi (2 c k1) / M); the table covers [0, M)
+        const cplx<T> w = tw[j2 & (M - 1)];
+        y = cmul(y, (j2 & M) ? mk<T>(-w.x, -w.y) : w);
+      }
+      d[k1 * RS] = y;
+    }
+  }
+  __syncthreads();
+  // step 2: rows
+  for (int q = tid; q < G * R; q += kStftThreads) {
+    const int g = q >> LOG2R, k1 = q & (R - 1);
+    cplx<T>* __restrict__ d = data + (size_t)g * TILE + k1 * RS;
+    cplx<T> v[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) v[j] = d[j];
+    native::fft_reg<T, C, -1>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < C; ++k2) d[k2] = v[native::brev(k2, LOG2C)];
+  }
+  __syncthreads();
+
+  // untangle and store: X[k] = (Z[k] + conj Z[M-k]) / 2 - (i / 2) exp(-i pi k / M) (Z[k] - conj Z[M-k]), Z[M] = Z[0];
+  // Z[k] = row k mod R, column k / R.  Consecutive threads take consecutive segments of one bin.
+  const int nf = M + 1, lg = a.log2g;
+  const T scale = (T)a.scale, eps = (T)a.eps;
+  for (int q = tid; q < (nf << lg); q += kStftThreads) {
+    const int k = q >> lg, g = q & (G - 1);
+    const int64_t m = m0 + g;
+    if (m >= a.nseg) continue;
+    const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
+    const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+    const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
+    const cplx<T> e = mk<T>(T(0.5) * (za.x + zb.x), T(0.5) * (za.y - zb.y));   // (Z[k] + conj Z[M-k]) / 2
+    const cplx<T> o = mk<T>(T(0.5) * (za.x - zb.x), T(0.5) * (za.y + zb.y));   // (Z[k] - conj Z[M-k]) / 2
+    const cplx<T> w = k < M ? tw[k] : mk<T>(T(-1), T(0));
+    const cplx<T> wo = cmul(o, w);
+    cplx<T> X = mk<T>(e.x + wo.y, e.y - wo.x);  // e - i (w o)
+    X.x *= scale;
+    X.y *= scale;
+    const int64_t at = (c * nf + k) * a.nseg + m;
+    Z[at] = X;
+    if (bits) bits[at] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
+  }
+}
+
+}  // namespace
+
+// M = R x C per transform length (R <= C <= 64: register transforms of at most 64 points; float64 keeps to 32)
+template <typename T>
+static bool stft_shape(int64_t M, int* lr, int* lc) {
+  int lm = 0;
+  while ((1ll << lm) < M) ++lm;
+  *lr = lm / 2;
+  *lc = lm - *lr;
+  return (1ll << lm) == M && *lc <= (sizeof(T) == 8 ? 5 : 6) && *lr >= 2;
+}
+
+// segments per workgroup (a power of two <= 16) so that the tiles and the twiddles stay within `budget` bytes of LDS
+static int stft_fused_group(int64_t M, int lr, int lc, size_t esz, size_t budget) {
+  const size_t tile = ((size_t)1 << lr) * (((size_t)1 << lc) + 1) + 1;
+  for (int G = 16; G >= 1; G >>= 1)
+    if (((size_t)G * tile + M) * esz <= budget) return G;
+  return 0;
+}
+
+bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft) {
+  int lr, lc;
+  if (!(nfft >= 64 && nfft <= 4096 && (nfft & (nfft - 1)) == 0 && seg <= nfft && seg >= 2 && hop >= 1)) return false;
+  return dtype == QI_F64 ? stft_shape<double>(nfft / 2, &lr, &lc) : stft_shape<float>(nfft / 2, &lr, &lc);
+}
+
+template <typename T, int LR, int LC>
+static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t nseg, StftFusedArgs a,
+                             hipStream_t st) {
+  const int64_t M = 1ll << (LR + LC);
+  const int G = stft_fused_group(M, LR, LC, sizeof(cplx<T>), 80 * 1024);  // two workgroups per CU
+  if (G < 1) {
+    set_error("fused STFT: a transform of %lld points does not fit the LDS tile", (long long)(2 * M));
+    return QI_ERR_UNSUPPORTED;
+  }
+  a.G = G;
+  a.log2g = 0;
+  while ((1 << a.log2g) < G) ++a.log2g;
+  const size_t tile = ((size_t)1 << LR) * (((size_t)1 << LC) + 1) + 1;
+  const size_t lds = ((size_t)G * tile + M) * sizeof(cplx<T>);
+  static bool raised = false;  // per instantiation: allow more than the default 64 KB of dynamic LDS once
+  if (!raised && lds > 48 * 1024) {
+    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    raised = true;
+  }
+  dim3 grid((unsigned)ceil_div(nseg, G), (unsigned)C);
+  k_stft_fused<T, LR, LC><<<grid, kStftThreads, lds, st>>>(sig, win, Z, bits, a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <typename T>
+int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st) {
+  StftFusedArgs a;
+  a.n = n;
+  a.seg = seg;
+  a.hop = hop;
+  a.nseg = nseg;
+  a.lead = lead;
+  a.scale = scale;
+  a.eps = eps;
+  a.G = a.log2g = 0;
+  int lr, lc;
+  if (!stft_shape<T>(nfft / 2, &lr, &lc)) {
+    set_error("fused STFT: transform length %lld is not supported", (long long)nfft);
+    return QI_ERR_UNSUPPORTED;
+  }
+  switch (lr * 8 + lc) {  // M = 32 ... 2048 (float64: ... 1024)
+    case 2 * 8 + 3: return launch_stft_shape<T, 2, 3>(sig, win, Z, bits, C, nseg, a, st);
+    case 3 * 8 + 3: return launch_stft_shape<T, 3, 3>(sig, win, Z, bits, C, nseg, a, st);
+    case 3 * 8 + 4: return launch_stft_shape<T, 3, 4>(sig, win, Z, bits, C, nseg, a, st);
+    case 4 * 8 + 4: return launch_stft_shape<T, 4, 4>(sig, win, Z, bits, C, nseg, a, st);
+    case 4 * 8 + 5: return launch_stft_shape<T, 4, 5>(sig, win, Z, bits, C, nseg, a, st);
+    case 5 * 8 + 5: return launch_stft_shape<T, 5, 5>(sig, win, Z, bits, C, nseg, a, st);
+    case 5 * 8 + 6:
+      if constexpr (sizeof(T) == 4) return launch_stft_shape<T, 5, 6>(sig, win, Z, bits, C, nseg, a, st);
+      break;
+    default: break;
+  }
+  set_error("fused STFT: transform length %lld is not supported", (long long)nfft);
+  return QI_ERR_UNSUPPORTED;
+}
+
+template int launch_stft_fused<float>(const float*, const float*, float2*, float*, int64_t, int64_t, int64_t, int64_t,
+                                      int64_t, int64_t, int64_t, double, double, hipStream_t);
+template int launch_stft_fused<double>(const double*, const double*, double2*, double*, int64_t, int64_t, int64_t, int64_t,
+                                       int64_t, int64_t, int64_t, double, double, hipStream_t);
+
+}  // namespace qi
