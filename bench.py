@@ -34,7 +34,11 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-CONFIGS = {1: dict(channels=1, order=3.0, stft=0), 2: dict(channels=64, order=12.0, stft=1)}
+CONFIGS = {1: dict(channels=1, order=3.0, stft=0), 2: dict(channels=64, order=12.0, stft=1),
+           # configs[4]: 24 h of 800 Hz infrasound (69 120 000 samples) x 1024 channels, chunks of 2^20 with a hop of 2^19, fp64,
+           # streamed from the host.  The bench streams a bounded sample per GPU (a block of 16 of the 128 channels a GPU
+           # would own, `--stream-chunks` of their 131 chunks) and reports the rate; steps = items.
+           4: dict(channels=16, order=12.0, stft=0, dtype="f64", fs=800.0, stream=1)}
 
 
 def parse():
@@ -50,8 +54,10 @@ def parse():
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--order", type=float, default=None)
     ap.add_argument("--stft", type=int, default=None, help="1: the order-N STFT of every record is part of the step")
-    ap.add_argument("--fs", type=float, default=1000.0)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--fs", type=float, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
+    ap.add_argument("--stream", type=int, default=None, help="1: records streamed from the host in overlapped chunks (config 4)")
+    ap.add_argument("--stream-chunks", type=int, default=6, help="chunks of the streaming sample (a 24 h record has 131)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU leg (0: min(16, cores))")
     ap.add_argument("--engine", default="auto", choices=["auto", "hipfft", "native"])
@@ -61,6 +67,9 @@ def parse():
     for k, v in cfg.items():
         if getattr(a, k) is None:
             setattr(a, k, v)
+    a.fs = 1000.0 if a.fs is None else a.fs
+    a.dtype = a.dtype or "f32"
+    a.stream = a.stream or 0
     if a.steps is None:
         a.steps = 200 if a.channels * a.order <= 12 else 20
     if a.warmup is None:
@@ -139,6 +148,102 @@ def cpu_baseline(args, n, fs, order):
     }
 
 
+def stream_bench(args, world, rank, local, cpu):
+    """BASELINE configs[4] as a bounded sample: float64 records on the host, overlapped chunks, the double-buffered
+    pipeline of quantum_inferno_amd.stream (pinned staging + copy stream), reduced products only, items sharded over the
+    ranks.  One step = one (channel block, chunk) item: CWT + STX + entropy of `channels` records of 2^20 samples."""
+    import torch
+    import torch.distributed as dist
+
+    import quantum_inferno_amd as qi
+    from quantum_inferno_amd import dist as qdist, stream, synth
+
+    dev = torch.device("cuda", local)
+    n, fs, order = 1 << args.log2n, args.fs, args.order
+    hop = n // 2
+    tdtype = torch.float32 if args.dtype == "f32" else torch.float64
+    npd = np.float32 if args.dtype == "f32" else np.float64
+    real_bytes = 4 if args.dtype == "f32" else 8
+    n_ch = args.channels
+    n_b = len(qi.scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    chunks = max(args.stream_chunks, args.warmup + 2)
+    total = n + (chunks - 1) * hop
+    # every rank streams its own block of records (weak scaling: the 24 h job has 128 channels x 131 chunks per GPU)
+    host = np.empty((n_ch, total), dtype=npd)
+    base = synth.log_chirp(n, fs, rank, max(world, 1), npd)
+    rng = np.random.default_rng(1000 + rank)
+    for c in range(n_ch):
+        reps = -(-total // n)
+        host[c] = np.tile(np.roll(base, 7919 * c), reps)[:total] + 0.01 * rng.standard_normal(total)
+    plan = qi.TfrPlan(n, tdtype, dev, qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=32 << 30))
+    plan.set_styx_bank(order, fs)
+    plan.set_stx_bands(order, fs)
+    pipe = stream.StreamPipeline(plan, host, hop, block=n_ch, transforms=("cwt", "stx"), keep_time=False)
+    items = len(pipe.items)
+    warm = min(args.warmup, items - 1)
+    it = pipe.run()
+    for _ in range(warm):
+        next(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    done, entropy = 0, 0.0
+    for item in it:
+        entropy += float(item.cwt.stats[0, 1])  # (touch the result: the item is complete)
+        done += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_local = time.perf_counter() - t0
+    rank_dt = [dt_local]
+    dt = dt_local
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_dt = [float(v.item()) for v in every]
+        dt = max(rank_dt)
+    if rank == 0:
+        points_item = 2 * n_ch * n_b * n
+        value = points_item * done * world / dt / 1e6
+        # plain host -> device copy rate of one item (pinned), for the PCIe share of a step
+        x = torch.empty((n_ch, n), dtype=tdtype).pin_memory()
+        d = torch.empty((n_ch, n), dtype=tdtype, device=dev)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(5):
+            d.copy_(x, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - tc) / 5 * 1e3
+        full_items = 128 * 131 / n_ch  # items one GPU of eight owns in the 24 h x 1024-channel job at this block size
+        line = {
+            "metric": "TFR Mpoints/sec (CWT+STX+entropy)", "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world,
+            "steps": done, "warmup": warm, "ms_per_step": round(dt / max(done, 1) * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[4] (bounded sample): float64 records streamed from the host, chunks of 2^{args.log2n} "
+                            f"samples with a hop of 2^{args.log2n - 1} @ {fs:g} Hz, order N={order:g}, CWT+STX+entropy ({n_b} bands), "
+                            f"reduced products only; {n_ch} records x {items} chunks per GPU here, 128 x 131 in the 24 h job",
+                "channels_per_gpu": n_ch, "n": n, "bands": n_b, "points_per_step": points_item * world, "world_size": world,
+                "rank_seconds": [round(v, 6) for v in rank_dt],
+                "h2d_ms_per_item": round(h2d_ms, 3),
+                "projected_seconds_24h_1024ch_8gpu": round(full_items * dt / max(done, 1), 1),
+            },
+            "step_roofline": {
+                "required_bytes_per_step": int(2 * (n_ch * n * real_bytes + n_ch * (n_b + n) * real_bytes)),
+                "note": "no panel is stored in streaming mode: the required HBM bytes are the records and the marginals only; "
+                        "the step is bound by the float64 two-pass kernels (see --dtype f64 for their stage breakdown)",
+            },
+        }
+        if cpu:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,6 +266,8 @@ def main():
     import quantum_inferno_amd as qi
     from quantum_inferno_amd import _lib, dist as qdist, styx_fft, synth
 
+    if args.stream:
+        return stream_bench(args, world, rank, local, cpu)
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
     real_bytes = 4 if args.dtype == "f32" else 8
     n_ch = args.channels

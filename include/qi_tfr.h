@@ -108,6 +108,11 @@ int qi_plan_set_gabor_bank(qi_plan* plan, int bank, int32_t n_bands, const doubl
 int qi_gabor_atoms(int device, int64_t n, int32_t n_bands, const double* p_re, const double* p_im,
                    const double* omega, const double* amp, void* out, qi_stream stream);
 
+/* The same on the caller's own sample positions x [n] (device, float64; x_k = fs * (t_k - t_offset) in samples):
+ * styx_cwt.wavelet_complex on an arbitrary time axis (styx_cwt.py:58-110), cwt_atoms.chirp_complex (cwt_atoms.py:16-50). */
+int qi_gabor_atoms_at(int device, int64_t n, int32_t n_bands, const double* p_re, const double* p_im,
+                      const double* omega, const double* amp, const void* x, void* out, qi_stream stream);
+
 /* Stockwell band table: shift index idx_j = argmin_k |fftfreq_k - f_j| and Gaussian width
  * sigma_j = M / (2 pi f_j / fs); the window exp(-sigma_j^2 omega_k^2 / 2), omega_k = 2 pi fftfreq_k / fs,
  * is regenerated in registers.  styx_stx.py:216-234.  Host arrays of length B. */
@@ -191,6 +196,11 @@ int64_t qi_power_marginals_scratch_bytes(int64_t n_channels, int64_t n_bands, in
  * `ref` is a device array [C] float64 or NULL (= 0).  Elements per channel = count. */
 int qi_log2_offset(int dtype, int device, const void* in, void* out, int64_t n_channels, int64_t count, double eps,
                    const void* ref, qi_stream stream);
+
+/* out[i] = log2(|in[i]| + eps) for `count` real (is_complex = 0) or complex (1; dtype is the real type) values:
+ * utilities.rescaling.to_log2_with_epsilon (utilities/rescaling.py:13-20) on a device array. */
+int qi_log2_abs(int dtype, int device, const void* in, int is_complex, void* out, int64_t count, double eps,
+                qi_stream stream);
 
 /* ShannonStft family (tfr_info.py:203-260) on P [C][B][n]:
  *   pdf = P * mult, mult = 1/sum(P)            (mode 0, shannon_stft_from_tfr_power)

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "qi_plan_destroy": (_int, [_P]),
     "qi_plan_set_gabor_bank": (_int, [_P, _int, _i32, _D, _D, _D, _D, _P]),
     "qi_gabor_atoms": (_int, [_int, _i64, _i32, _D, _D, _D, _D, _P, _P]),
+    "qi_gabor_atoms_at": (_int, [_int, _i64, _i32, _D, _D, _D, _D, _P, _P, _P]),
     "qi_plan_set_stx_bands": (_int, [_P, _i32, _I64, _D]),
     "qi_plan_bands": (_i64, [_P, _int]),
     "qi_plan_stage_bands": (_i64, [_P, _int, _int]),
@@ -71,6 +72,7 @@ PROTOTYPES = {
     "qi_power_marginals": (_int, [_int, _int, _P, _i64, _i64, _i64, _P, _P, _P, _P, _i64, _P]),
     "qi_power_marginals_scratch_bytes": (_i64, [_i64, _i64, _i64]),
     "qi_log2_offset": (_int, [_int, _int, _P, _P, _i64, _i64, _dbl, _P, _P]),
+    "qi_log2_abs": (_int, [_int, _int, _P, _int, _P, _i64, _dbl, _P]),
     "qi_shannon_panel": (_int, [_int, _int, _P, _P, _int, _i64, _i64, _i64, _dbl, _P, _P, _P, _P, _P]),
     "qi_sliding_scratch_bytes": (_i64, [_int, _i64, _i64, _i64]),
     "qi_sliding_stft": (_int, [_int, _int, _P, _i64, _i64, _P, _i64, _i64, _i64, _i64, _i64, _int, _int, _i64, _P, _P, _int, _P, _i64, _P]),

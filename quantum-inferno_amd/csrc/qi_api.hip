@@ -43,6 +43,7 @@ struct FftCache {
   std::map<Key, hipfftHandle> plans;
   void* work = nullptr;
   size_t work_bytes = 0;
+  std::vector<void*> retired;  // outgrown work areas, freed with the cache
 
   int get(hipfftType type, int64_t len, int64_t batch, hipfftHandle* out) {
     Key k{(int)type, len, batch};
@@ -59,9 +60,9 @@ struct FftCache {
     size_t ws = 0;
     QI_FFT(hipfftMakePlanMany(h, 1, nn, nullptr, 1, (int)len, nullptr, 1, (int)len, type, (int)batch, &ws));
     if (ws > work_bytes) {
-      // growing the shared work area happens while a plan warms up, never in steady state
-      QI_HIP(hipDeviceSynchronize());
-      if (work) QI_HIP(hipFree(work));
+      // growing the shared work area happens while a plan warms up, never in steady state.  No synchronisation: the old
+      // area stays allocated (transforms already queued keep using it) until the cache is cleared
+      if (work) retired.push_back(work);
       work = nullptr;
       work_bytes = 0;
       QI_HIP(hipMalloc(&work, ws));
@@ -77,6 +78,8 @@ struct FftCache {
     for (auto& kv : plans) hipfftDestroy(kv.second);
     plans.clear();
     if (work) (void)hipFree(work);
+    for (void* w : retired) (void)hipFree(w);
+    retired.clear();
     work = nullptr;
     work_bytes = 0;
   }
@@ -340,6 +343,7 @@ struct qi_plan {
   int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
                            // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
                            // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
+  int native_f64 = 1;      // float64 plans run the two-pass kernels (exact algorithm, double arithmetic) at 2^20 / 2^21-point transforms
   int native_gather_fused = 4;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
                                 // (no gather launch, two passes over the coarse storage fewer: -30 % of that stage at 16 records);
                                 // below it the gather launch's 16 x more workgroups win (one record: 28 vs 43 us); 0: never
@@ -517,8 +521,10 @@ bool native_len_ok(int64_t Lf) { return Lf == (1ll << 20) || Lf == (1ll << 21); 
 
 // does this plan run transform `kind` (0 styx bank, 1 atoms bank, 2 Stockwell) on the native engine?
 bool native_wanted(const qi_plan* p, int kind) {
-  if (p->d.engine == QI_ENGINE_HIPFFT || p->d.dtype != QI_F32) return false;
+  if (p->d.engine == QI_ENGINE_HIPFFT) return false;
   const int64_t Lf = kind == 0 ? p->L : p->n;
+  // float64: the exact two-pass kernels only (their transform lengths); no zoom / block / split approximations
+  if (p->d.dtype == QI_F64) return p->native_f64 && is_pow2(p->n) && native_len_ok(Lf);
   if (is_pow2(p->n) && native_len_ok(Lf)) return true;
   // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
   // band), and those engines take any power-of-two length from 2^18: the table build decides
@@ -648,7 +654,8 @@ int analyse_support(qi_plan* p, int circular, int64_t L, int32_t B, int32_t j0, 
   double2* rows = reinterpret_cast<double2*>(p->ws);
   double* d_sup = nullptr;
   QI_HIP(hipMalloc((void**)&d_sup, (size_t)count * 3 * sizeof(double)));
-  const double thr2 = std::ldexp(1.0, -60);  // |H| below 2^-30 of the row maximum is dropped
+  // |H| below 2^-30 of the row maximum is dropped (float32 engines); float64 keeps everything above 2^-50
+  const double thr2 = p->d.dtype == QI_F64 ? std::ldexp(1.0, -100) : std::ldexp(1.0, -60);
   int rc = QI_OK;
   for (int32_t q = 0; q < count && rc == QI_OK; q += (int32_t)chunk) {
     const int nbk = (count - q < chunk) ? count - q : (int)chunk;
@@ -1732,6 +1739,124 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   return QI_OK;
 }
 
+// float64 records on the native two-pass kernels (exact algorithm: no truncated atoms, no interpolation): forward
+// transform of the records by hipFFT, then per launch group pass 1 for the wide bands and pass 2 with the pruned loader
+// and the fused epilogue for every band, one tail launch.  8-row workgroups (Cfg<double, 8>).
+int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
+  using T = double;
+  const auto& t = p->nat[kind];
+  const int64_t n = p->n, B = t.nbands, Lf = t.Lf;
+  constexpr int G = 8;
+  const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
+  const T* sig = static_cast<const T*>(sig_v);
+  std::vector<int> nchunk;
+  int chunk_total = 0;
+  for (const auto& grp : t.groups) {
+    int nc = (int)ceil_div(p->native_wgs, nblk * C);
+    nc = nc < 1 ? 1 : (nc > grp.count ? grp.count : nc);
+    nchunk.push_back(nc);
+    chunk_total += nc;
+  }
+  if (chunk_total == 0) {
+    set_error("float64 native table has no band");
+    return QI_ERR_STATE;
+  }
+  const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr, want_time = out->power_time != nullptr;
+  const bool time_via_part = want_time && chunk_total > 1;
+  const int64_t stat_slots = (int64_t)chunk_total * nblk;
+  const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
+  const size_t e_imd = (size_t)t.imd_slots * Lf * sizeof(cplx<T>);
+  const size_t e_pb = (size_t)B * nblk * 8, e_ps = (size_t)stat_slots * 24;
+  const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
+  const size_t per_chan = e_x + e_imd + e_pb + e_ps + e_tp;
+  if (p->ws_bytes < per_chan + 4096) {
+    set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 4096);
+    return QI_ERR_NOMEM;
+  }
+  int64_t Ct = (int64_t)((p->ws_bytes - 4096) / per_chan);
+  if (Ct > C) Ct = C;
+  p->shared_valid = false;
+  char* w = p->ws;
+  auto carve = [&](size_t bytes) {
+    char* r = w;
+    w += align_up(bytes * Ct);
+    return r;
+  };
+  cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
+  cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
+  double* part_band = reinterpret_cast<double*>(carve(e_pb));
+  double* part_stat = reinterpret_cast<double*>(carve(e_ps));
+  T* time_part = reinterpret_cast<T*>(carve(e_tp));
+  for (int64_t c0 = 0; c0 < C; c0 += Ct) {
+    const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
+    p->prof.begin(st, QI_STAGE_FORWARD);
+    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
+    QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    p->prof.end(QI_STAGE_FORWARD, st);
+    native::RowArgs<T> a{};
+    a.Lf = Lf;
+    a.n = n;
+    a.N1 = N1;
+    a.N2 = native::kN2;
+    a.panel_bands = (int32_t)B;
+    a.imd_slots = t.imd_slots;
+    a.chunk_total = chunk_total;
+    a.X = X;
+    a.Hc = static_cast<const cplx<T>*>(t.Hc);
+    a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
+    a.imd = imd;
+    a.inv_len = 1.0 / (double)Lf;
+    a.two_over_len = (float)(2.0 / (double)Lf);
+    a.neg_last_row = kind == 0 ? 1 : 0;
+    a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+    a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+    a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+    a.part_band = want_band ? part_band : nullptr;
+    a.part_stat = want_stat ? part_stat : nullptr;
+    a.nblk = nblk;
+    a.stat_nblk = nblk;
+    a.stat_stride = stat_slots;
+    a.power_scale = out->power_scale == 0.0 ? 1.0 : out->power_scale;
+    a.eps = out->eps == 0.0 ? 2.220446049250313e-16 : out->eps;
+    int chunk_base = 0;
+    for (size_t g = 0; g < t.groups.size(); ++g) {
+      const auto& grp = t.groups[g];
+      a.bands = t.d_bands + grp.first;
+      a.nbands = grp.count;
+      a.gen_list = t.d_gen_list ? t.d_gen_list + grp.gen_first : nullptr;
+      a.ngen_launch = grp.ngen;
+      a.chunk_base = chunk_base;
+      if (grp.ngen > 0) {
+        p->prof.begin(st, QI_STAGE_PASS1);
+        QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
+        p->prof.end(QI_STAGE_PASS1, st);
+      }
+      p->prof.begin(st, QI_STAGE_PASS2);
+      QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk[g], ct, st));
+      p->prof.end(QI_STAGE_PASS2, st);
+      chunk_base += nchunk[g];
+    }
+    p->prof.begin(st, QI_STAGE_EPILOGUE);
+    double* pb_out = want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr;
+    double* st_out = want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr;
+    if (time_via_part && (want_band || want_stat)) {
+      QI_TRY(native::launch_tail<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total, nullptr, 0,
+                                    want_band ? part_band : nullptr, want_stat ? part_stat : nullptr, pb_out, st_out, B, nblk,
+                                    stat_slots, nullptr, st));
+    } else {
+      if (time_via_part)
+        QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
+                                             nullptr, 0, st));
+      if (want_band || want_stat)
+        QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr, pb_out, st_out, ct, B, nblk,
+                               stat_slots, st, nullptr));
+    }
+    p->prof.end(QI_STAGE_EPILOGUE, st);
+    p->prof.unchain();
+  }
+  return QI_OK;
+}
+
 template <typename T>
 int build_bank(qi_plan* p, int bank, int32_t B, const double* d_par, hipStream_t st) {
   const int64_t n = p->n;
@@ -1864,8 +1989,9 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   QI_REQUIRE(desc->n >= 2 && desc->n <= (1ll << 28), "n = %lld out of range", (long long)desc->n);
   QI_REQUIRE(desc->dtype == QI_F32 || desc->dtype == QI_F64, "bad dtype %d", desc->dtype);
   QI_REQUIRE(desc->engine >= QI_ENGINE_AUTO && desc->engine <= QI_ENGINE_NATIVE, "bad engine %d", desc->engine);
-  if (desc->engine == QI_ENGINE_NATIVE && !(desc->dtype == QI_F32 && is_pow2(desc->n) && desc->n >= (1 << 18))) {
-    set_error("native engine: float32 records of a power-of-two length >= 2^18 only (got n = %lld, dtype %d)",
+  if (desc->engine == QI_ENGINE_NATIVE && !(is_pow2(desc->n) && desc->n >= (1 << 18) &&
+                                            (desc->dtype == QI_F32 || desc->n == (1 << 20)))) {
+    set_error("native engine: float32 records of a power-of-two length >= 2^18, float64 records of 2^20 samples (got n = %lld, dtype %d)",
               (long long)desc->n, desc->dtype);
     return QI_ERR_UNSUPPORTED;
   }
@@ -1924,6 +2050,12 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = getenv("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
+  }
+  if (const char* e = getenv("QI_NATIVE_F64")) p->native_f64 = atoi(e);
+  if (desc->dtype == QI_F64) {  // exact paths only: every band on the two-pass kernels, evaluated at the full length
+    p->native_zoom = p->native_block = p->native_short = p->native_split = 0;
+    p->native_rows = 8;
+    if (p->native_group <= 0) p->native_group = 8;  // wide bands per launch group: bounds the intermediate (32 MB per band and record)
   }
   p->ws_bytes = desc->workspace_bytes > 0 ? (size_t)desc->workspace_bytes : ((size_t)2 << 30);
   if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {
@@ -2042,7 +2174,8 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     rc = QI_ERR_HIP;
   }
   if (rc == QI_OK && use_native) {
-    rc = build_native_bank<float>(p, bank, B, d_par, host.data(), st);
+    rc = p->d.dtype == QI_F64 ? build_native_bank<double>(p, bank, B, d_par, host.data(), st)
+                              : build_native_bank<float>(p, bank, B, d_par, host.data(), st);
     // The zoom and block engines take any power-of-two record from 2^18 samples; the two-pass kernels run
     // 2^20 / 2^21-point transforms only.  A table that still has bands for them at another length goes to the hipFFT engine.
     if (rc == QI_OK && !native_len_ok(L) && !p->nat[bank].h_rows.empty()) {
@@ -2073,7 +2206,20 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
     rc = QI_ERR_HIP;
   }
   (void)hipFree(d_par);
-  if (rc == QI_OK) p->nb[bank] = B;
+  if (rc == QI_OK) {
+    p->nb[bank] = B;
+  } else {  // nothing half-built stays behind (a ready table without its block / split producers would leave rows unwritten)
+    p->nat[bank].release();
+    if (bank == QI_BANK_STYX) {
+      p->blk[0].release();
+      p->nat[3].release();
+      p->nsplit = 0;
+    }
+    if (p->bank[bank]) {
+      (void)hipFree(p->bank[bank]);
+      p->bank[bank] = nullptr;
+    }
+  }
   return rc;
 }
 
@@ -2105,6 +2251,35 @@ int qi_gabor_atoms(int device, int64_t n, int32_t B, const double* p_re, const d
   return rc;
 }
 
+int qi_gabor_atoms_at(int device, int64_t n, int32_t B, const double* p_re, const double* p_im, const double* omega,
+                      const double* amp, const void* x, void* out, qi_stream stream) {
+  QI_REQUIRE(p_re && p_im && omega && amp && x && out, "null argument");
+  QI_REQUIRE(n >= 1 && B > 0 && B <= 65535, "bad atom bank shape");
+  DeviceGuard g(device);
+  double* d_par = nullptr;
+  QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
+  std::vector<double> host((size_t)4 * B);
+  memcpy(&host[0], p_re, B * sizeof(double));
+  memcpy(&host[B], p_im, B * sizeof(double));
+  memcpy(&host[2 * B], omega, B * sizeof(double));
+  memcpy(&host[3 * B], amp, B * sizeof(double));
+  int rc = QI_OK;
+  if (hipMemcpy(d_par, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy of band parameters failed");
+    rc = QI_ERR_HIP;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (rc == QI_OK)
+    rc = launch_bank_rows((double2*)out, n, n, 1, d_par, d_par + B, d_par + 2 * B, d_par + 3 * B, 0, B, st, 0.0,
+                          static_cast<const double*>(x));
+  if (rc == QI_OK && hipStreamSynchronize(st) != hipSuccess) {
+    set_error("atom kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    rc = QI_ERR_HIP;
+  }
+  (void)hipFree(d_par);
+  return rc;
+}
+
 int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, const double* sigma) {
   QI_REQUIRE(p && shift_index && sigma, "null argument");
   QI_REQUIRE(B > 0 && B <= 65535, "band count %d out of range", B);
@@ -2127,7 +2302,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
   QI_HIP(hipMalloc((void**)&p->d_stx_coef, B * sizeof(double)));
   QI_HIP(hipMemcpy(p->d_stx_idx, shift_index, B * sizeof(int64_t), hipMemcpyHostToDevice));
   QI_HIP(hipMemcpy(p->d_stx_coef, coef.data(), B * sizeof(double), hipMemcpyHostToDevice));
-  p->nb_stx = B;
+  p->nb_stx = 0;  // committed below, once every table of the native engine has been built
   p->nat[2].release();
   p->blk[2].release();
   if (p->d_band_slots[2]) {
@@ -2135,7 +2310,8 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     p->d_band_slots[2] = nullptr;
   }
   if (native_wanted(p, 2)) {
-    // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef
+    // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef (float64: above 2^-50)
+    const double cut = p->d.dtype == QI_F64 ? std::sqrt(50.0) : std::sqrt(30.0);
     std::vector<native::BandDesc> bands;
     std::vector<BlockPick> picks;
     const bool can_block = p->native_block && p->n >= 4 * native::kBlk;
@@ -2164,7 +2340,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       d.shift = shift_index[j];
       d.coef = coef[j];
       d.out_band = j;
-      const double kh = std::floor(std::sqrt(30.0) / coef[j]);
+      const double kh = std::floor(cut / coef[j]);
       const int zc = 2 * kh + 1 < (double)p->n ? zoom_class(p, 2, p->n, (int64_t)(2 * kh + 1)) : -1;
       if (zc >= 0 || (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n)) {
         d.mode = zc >= 0 ? 2 + zc : 0;
@@ -2178,9 +2354,16 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     bool two_pass_free = true;  // no band for pass 1 / pass 2 (their transform lengths are 2^20 and 2^21 only)
     for (const auto& d : bands) two_pass_free = two_pass_free && d.mode >= 2;
     if (native_len_ok(p->n) || two_pass_free) {
-      QI_TRY(upload_native_table(p, 2, p->n, bands));
-      p->nat[2].nbands = B;
-      QI_TRY(build_block_stx<float>(p, picks, coef, nullptr));
+      int rc = upload_native_table(p, 2, p->n, bands);
+      if (rc == QI_OK) {
+        p->nat[2].nbands = B;
+        rc = build_block_stx<float>(p, picks, coef, nullptr);
+      }
+      if (rc != QI_OK) {  // no half-built table: a ready table whose block bands have no producer would leave panel rows unwritten
+        p->nat[2].release();
+        p->blk[2].release();
+        return rc;
+      }
     } else if (p->d.engine == QI_ENGINE_NATIVE) {
       set_error("native engine: this Stockwell band table needs the two-pass kernels, which run 2^20 / 2^21 samples only");
       return QI_ERR_UNSUPPORTED;
@@ -2189,6 +2372,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     set_error("native engine does not support the Stockwell transform at n = %lld", (long long)p->n);
     return QI_ERR_UNSUPPORTED;
   }
+  p->nb_stx = B;
   return QI_OK;
 }
 
@@ -2238,7 +2422,9 @@ int qi_cwt(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_out* o
   DeviceGuard g(p->d.device);
   const Kind k = bank == QI_BANK_STYX ? Kind::Linear : Kind::Circular;
   p->prof.unchain();
-  if (p->nat[bank].ready) return run_native<float>(p, bank, sig, C, out, (hipStream_t)stream);
+  if (p->nat[bank].ready)
+    return p->d.dtype == QI_F64 ? run_native64(p, bank, sig, C, out, (hipStream_t)stream)
+                                : run_native<float>(p, bank, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, k, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, k, sig, C, out, (hipStream_t)stream);
 }
@@ -2248,7 +2434,9 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
   p->prof.unchain();
-  if (p->nat[2].ready) return run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
+  if (p->nat[2].ready)
+    return p->d.dtype == QI_F64 ? run_native64(p, 2, sig, C, out, (hipStream_t)stream)
+                                : run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
   return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
 }
@@ -2269,7 +2457,7 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
                qi_stream stream) {
   QI_REQUIRE(p && sig && out_cwt && out_stx, "null argument");
   QI_REQUIRE(bank == QI_BANK_STYX, "qi_cwt_stx runs the styx bank (bank %d given)", bank);
-  const bool fuse = p->native_fuse && p->nat[bank].ready && p->nat[2].ready;
+  const bool fuse = p->native_fuse && p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready;
   p->carry.active = false;
   p->carry.has_zoom = false;
   QI_REQUIRE(C > 0, "n_channels must be positive");
@@ -2313,7 +2501,7 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
     }
   }
   QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
-  if (p->nat[bank].ready && p->nat[2].ready) {  // separate launches, but the Stockwell run may still use the CWT's spectra
+  if (p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready) {  // separate launches, but the Stockwell run may still use the CWT's spectra
     DeviceGuard g(p->d.device);
     p->prof.unchain();
     const int rc = run_native<float>(p, 2, sig, C, out_stx, st, /*may_share=*/true, nullptr, nullptr);
@@ -2407,6 +2595,16 @@ int qi_log2_offset(int dtype, int device, const void* in, void* out, int64_t C, 
                                                       (const double*)ref, (hipStream_t)stream)
                          : launch_log2_offset<float>((const float*)in, (float*)out, C, count, (float)eps,
                                                      (const double*)ref, (hipStream_t)stream);
+}
+
+int qi_log2_abs(int dtype, int device, const void* in, int is_complex, void* out, int64_t count, double eps,
+                qi_stream stream) {
+  QI_REQUIRE(in && out, "null argument");
+  QI_REQUIRE(dtype == QI_F32 || dtype == QI_F64, "bad dtype %d", dtype);
+  QI_REQUIRE(count > 0, "bad shape");
+  DeviceGuard g(device);
+  return dtype == QI_F64 ? launch_log2_abs<double>((const double*)in, is_complex, (double*)out, count, eps, (hipStream_t)stream)
+                         : launch_log2_abs<float>((const float*)in, is_complex, (float*)out, count, (float)eps, (hipStream_t)stream);
 }
 
 int qi_shannon_panel(int dtype, int device, const void* power, const void* mult, int mode, int64_t C, int64_t B,

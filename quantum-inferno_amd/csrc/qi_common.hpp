@@ -91,7 +91,8 @@ template <typename T>
 int launch_pack_pad(const T* sig, cplx<T>* X, int64_t C, int64_t n, int64_t L, hipStream_t st);
 
 int launch_bank_rows(double2* rows, int64_t n, int64_t L, int circular, const double* p_re, const double* p_im,
-                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e = 0.0);
+                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e = 0.0,
+                     const double* xs = nullptr);
 template <typename T>
 int launch_bank_convert(const double2* F, cplx<T>* bank, int64_t count, int conj, double scale, hipStream_t st);
 
@@ -167,6 +168,8 @@ int launch_power_marginals(const T* P, int64_t C, int64_t B, int64_t n, T* power
                            double* part_stat, hipStream_t st);
 template <typename T>
 int launch_log2_offset(const T* in, T* out, int64_t C, int64_t count, T eps, const double* ref, hipStream_t st);
+template <typename T>
+int launch_log2_abs(const T* in, int is_complex, T* out, int64_t count, T eps, hipStream_t st);
 template <typename T>
 int launch_shannon(const T* P, const T* mult, int mode, int64_t C, int64_t B, int64_t n, double deg, T* info, T* sb,
                    T* isnr, T* esnr, hipStream_t st);

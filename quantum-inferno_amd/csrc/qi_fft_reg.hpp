@@ -92,6 +92,35 @@ __device__ __forceinline__ void unit_root(uint32_t m, float two_over_len, double
   *s = sf;
 }
 
+// the same in the arithmetic of the engine's element type: float64 engines take the double-precision sincospi of the
+// (exact) argument
+template <typename T>
+__device__ __forceinline__ void unit_root_t(uint32_t m, float two_over_len, double* c, double* s) {
+  if constexpr (sizeof(T) == 8) {
+    double sd, cd;
+    sincospi((double)m * (double)two_over_len, &sd, &cd);
+    *c = cd;
+    *s = sd;
+  } else {
+    unit_root(m, two_over_len, c, s);
+  }
+}
+// sin / cos of pi x in the precision of T (x is formed exactly by the callers)
+template <typename T>
+__device__ __forceinline__ void sincospi_as(double x, T* s, T* c) {
+  if constexpr (sizeof(T) == 8) {
+    double sd, cd;
+    sincospi(x, &sd, &cd);
+    *s = sd;
+    *c = cd;
+  } else {
+    float sf, cf;
+    sincospif((float)x, &sf, &cf);
+    *s = sf;
+    *c = cf;
+  }
+}
+
 __device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
 __device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 

@@ -21,7 +21,8 @@ __global__ void k_pack_pad(const T* __restrict__ sig, cplx<T>* __restrict__ X, i
 // (the operand scipy.signal.fftconvolve receives, styx_cwt.py:195-196); circular mode the atom itself.
 __global__ void k_bank_rows(double2* __restrict__ rows, int64_t n, int64_t L, int circular,
                             const double* __restrict__ p_re, const double* __restrict__ p_im,
-                            const double* __restrict__ omega, const double* __restrict__ amp, int j0, double taper_e) {
+                            const double* __restrict__ omega, const double* __restrict__ amp, int j0, double taper_e,
+                            const double* __restrict__ xs) {
   int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int jj = blockIdx.y;
   int j = j0 + jj;
@@ -29,7 +30,7 @@ __global__ void k_bank_rows(double2* __restrict__ rows, int64_t n, int64_t L, in
   double2 v = make_double2(0.0, 0.0);
   if (m < n) {
     int64_t k = circular ? m : (n - 1 - m);
-    double x = (double)k - 0.5 * (double)(n - 1);
+    double x = xs ? xs[k] : (double)k - 0.5 * (double)(n - 1);  // xs: the caller's own sample positions (atoms for inspection)
     double g = amp[j] * exp(-p_re[j] * x * x);
     if (taper_e > 0.0) g *= split_taper(x, n, taper_e);  // the zoom-engine part of a split band
     double ph = omega[j] * x - p_im[j] * x * x;
@@ -268,6 +269,21 @@ __global__ void k_log2_offset(const T* __restrict__ in, T* __restrict__ out, int
     out[c * count + i] = log2_t(in[c * count + i] + eps) - r;
 }
 
+// out[i] = log2(|in[i]| + eps), in real (CPLX = false) or complex (utilities/rescaling.py:13-20)
+template <typename T, bool CPLX>
+__global__ void k_log2_abs(const T* __restrict__ in, T* __restrict__ out, int64_t count, T eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    T m;
+    if (CPLX) {
+      const T re = in[2 * i], im = in[2 * i + 1];
+      m = sqrt_t(re * re + im * im);
+    } else {
+      m = in[i] < T(0) ? -in[i] : in[i];
+    }
+    out[i] = log2_t(m + eps);
+  }
+}
+
 template <typename T>
 __global__ void k_shannon(const T* __restrict__ P, const T* __restrict__ mult, int mode, int64_t B, int64_t n,
                           T log2d, T inv_ref, T* __restrict__ info, T* __restrict__ sb, T* __restrict__ isnr,
@@ -310,9 +326,9 @@ int launch_pack_pad(const T* sig, cplx<T>* X, int64_t C, int64_t n, int64_t L, h
 }
 
 int launch_bank_rows(double2* rows, int64_t n, int64_t L, int circular, const double* p_re, const double* p_im,
-                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e) {
+                     const double* omega, const double* amp, int j0, int nb, hipStream_t st, double taper_e, const double* xs) {
   dim3 g((unsigned)ceil_div(L, 256), (unsigned)nb);
-  k_bank_rows<<<g, 256, 0, st>>>(rows, n, L, circular, p_re, p_im, omega, amp, j0, taper_e);
+  k_bank_rows<<<g, 256, 0, st>>>(rows, n, L, circular, p_re, p_im, omega, amp, j0, taper_e, xs);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
@@ -419,6 +435,18 @@ int launch_log2_offset(const T* in, T* out, int64_t C, int64_t count, T eps, con
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
+
+template <typename T>
+int launch_log2_abs(const T* in, int is_complex, T* out, int64_t count, T eps, hipStream_t st) {
+  int64_t blocks = ceil_div(count, 256);
+  if (blocks > 8192) blocks = 8192;
+  if (is_complex) k_log2_abs<T, true><<<(unsigned)blocks, 256, 0, st>>>(in, out, count, eps);
+  else k_log2_abs<T, false><<<(unsigned)blocks, 256, 0, st>>>(in, out, count, eps);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_log2_abs<float>(const float*, int, float*, int64_t, float, hipStream_t);
+template int launch_log2_abs<double>(const double*, int, double*, int64_t, double, hipStream_t);
 
 template <typename T>
 int launch_shannon(const T* P, const T* mult, int mode, int64_t C, int64_t B, int64_t n, double deg, T* info, T* sb,

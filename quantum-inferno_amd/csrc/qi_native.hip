@@ -80,7 +80,7 @@ __device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowA
   if (tid < MAXM * C::G) {
     const int m = tid / C::G, g = tid % C::G;
     double wr, wi;
-    unit_root(((uint32_t)((k1_min + m) * 1024) * (t1_0 + (uint32_t)g)) & mask, a.two_over_len, &wr, &wi);
+    unit_root_t<T>(((uint32_t)((k1_min + m) * 1024) * (t1_0 + (uint32_t)g)) & mask, a.two_over_len, &wr, &wi);
     tw1[tid] = mk<T>((T)wr, (T)wi);
   }
   __syncthreads();
@@ -137,8 +137,8 @@ __device__ __forceinline__ void load_pruned(cplx<T>* A, cplx<T>* tw1, const RowA
     const uint32_t sl = (uint32_t)(tid + q * C::TH);
     if (has[q]) {
       double wr, wi, sr, si;
-      unit_root((sl * t1v) & mask, a.two_over_len, &wr, &wi);
-      unit_root(sl & mask, a.two_over_len, &sr, &si);
+      unit_root_t<T>((sl * t1v) & mask, a.two_over_len, &wr, &wi);
+      unit_root_t<T>(sl & mask, a.two_over_len, &sr, &si);
 #pragma unroll
       for (int g = 0; g < C::G; ++g) {
         const T cr = (T)wr, ci = (T)wi;
@@ -214,9 +214,9 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
         if (ph == 0) {
           y = mk<T>(ys[u][0].x + ys[u][1].x, ys[u][0].y + ys[u][1].y);
         } else {
-          float sn, cs;
-          sincospif((float)m * (1.0f / 1024.0f), &sn, &cs);  // W_2048^m
-          y = cmul(mk<T>(ys[u][0].x - ys[u][1].x, ys[u][0].y - ys[u][1].y), mk<T>((T)cs, (T)sn));
+          T sn, cs;
+          sincospi_as<T>((double)m * (1.0 / 1024.0), &sn, &cs);  // W_2048^m
+          y = cmul(mk<T>(ys[u][0].x - ys[u][1].x, ys[u][0].y - ys[u][1].y), mk<T>(cs, sn));
         }
       }
       A[r * C::SR + m] = y;
@@ -229,15 +229,15 @@ __device__ __forceinline__ void load_full(cplx<T>* A, const RowArgs<T>& a, const
 template <typename T, class C>
 __device__ __forceinline__ void fill_step_twiddles(cplx<T>* tw) {
   for (int i = threadIdx.x; i < C::NR + C::TW2; i += C::TH) {
-    float sf, cf;
+    T sf, cf;
     if (i < C::NR) {
       const int d = i / 64, aa = i % 64;
-      sincospif((float)(2 * (aa * d)) / (float)C::NR, &sf, &cf);
+      sincospi_as<T>((double)(2 * (aa * d)) / (double)C::NR, &sf, &cf);
     } else {
       const int c2 = (i - C::NR) / 16, a1 = (i - C::NR) % 16;
-      sincospif((float)(2 * (a1 * c2)) / 64.0f, &sf, &cf);
+      sincospi_as<T>((double)(2 * (a1 * c2)) / 64.0, &sf, &cf);
     }
-    tw[i] = mk<T>((T)cf, (T)sf);
+    tw[i] = mk<T>(cf, sf);
   }
 }
 
@@ -356,14 +356,14 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
 #endif
     // pass twiddle W_Lf^(k2 t1) along t1 = NPH (d2 + 16 c2 + 64 c1) + ph by a float64 recurrence over c1
     double wr, wi, sr, si;
-    unit_root((k2 * (uint32_t)(NPH * (d2 + 16 * c2) + ph)) & mask, a.two_over_len, &wr, &wi);
-    unit_root((k2 * (uint32_t)(64 * NPH)) & mask, a.two_over_len, &sr, &si);
+    unit_root_t<T>((k2 * (uint32_t)(NPH * (d2 + 16 * c2) + ph)) & mask, a.two_over_len, &wr, &wi);
+    unit_root_t<T>((k2 * (uint32_t)(64 * NPH)) & mask, a.two_over_len, &sr, &si);
 #pragma unroll
     for (int c1 = 0; c1 < 16; ++c1) {
       const cplx<T> z = u[brev(c1, 4)];
       const uint32_t t1 = (uint32_t)(NPH * (d2 + 16 * c2 + 64 * c1)) + (uint32_t)ph;
       if (c1 == 15 && a.neg_last_row && t1 == cmask)  // t1 = N1 - 1 is used by pass 2 as t1 = -1
-        unit_root((0u - k2) & mask, a.two_over_len, &wr, &wi);
+        unit_root_t<T>((0u - k2) & mask, a.two_over_len, &wr, &wi);
       const T cr = (T)wr, ci = (T)wi;
       if (!QI_DBG(1)) dst[(size_t)((t1 + roll) & cmask) * kN2] = mk<T>(z.x * cr - z.y * ci, z.x * ci + z.y * cr);
       const double nr = wr * sr - wi * si;
@@ -890,14 +890,14 @@ static int launch_p2(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
   return a.bits ? launch_p2v<T, C, KIND, false, true>(a, grid, st) : launch_p2v<T, C, KIND, false, false>(a, grid, st);
 }
 
-template <class C>
-static int launch_pass1_cfg(const RowArgs<float>& a0, int kind, int64_t n_channels, hipStream_t st) {
-  RowArgs<float> a = a0;
+template <typename T, class C>
+static int launch_pass1_cfg(const RowArgs<T>& a0, int kind, int64_t n_channels, hipStream_t st) {
+  RowArgs<T> a = a0;
   a.phase_split = a.N1 == 2048 && (a.N2 / C::G) * a.ngen_launch * n_channels < 256 ? 1 : 0;
   dim3 grid((unsigned)(a.N2 / C::G), (unsigned)(a.ngen_launch * (a.phase_split ? 2 : 1)), (unsigned)n_channels);
   const bool stx = kind == 2;
-  if (a.N1 == 1024) return stx ? launch_p1<float, C, 1, 1>(a, grid, st) : launch_p1<float, C, 0, 1>(a, grid, st);
-  if (a.N1 == 2048) return stx ? launch_p1<float, C, 1, 2>(a, grid, st) : launch_p1<float, C, 0, 2>(a, grid, st);
+  if (a.N1 == 1024) return stx ? launch_p1<T, C, 1, 1>(a, grid, st) : launch_p1<T, C, 0, 1>(a, grid, st);
+  if (a.N1 == 2048) return stx ? launch_p1<T, C, 1, 2>(a, grid, st) : launch_p1<T, C, 0, 2>(a, grid, st);
   set_error("native pass 1 supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
   return QI_ERR_UNSUPPORTED;
 }
@@ -905,7 +905,14 @@ template <>
 int launch_pass1<float>(const RowArgs<float>& a, int kind, int64_t n_channels, hipStream_t st) {
   if (a.ngen_launch <= 0) return QI_OK;
   // (8-row workgroups were measured for launches that do not cover the chip: slower, their 64-byte runs cost more)
-  return launch_pass1_cfg<Cfg<float, 16>>(a, kind, n_channels, st);
+  return launch_pass1_cfg<float, Cfg<float, 16>>(a, kind, n_channels, st);
+}
+// float64: 8-row workgroups of 512 threads (the row transform holds 2 x 16 complex doubles per thread: 256-register
+// budget; LDS image 152 KB, one workgroup per CU)
+template <>
+int launch_pass1<double>(const RowArgs<double>& a, int kind, int64_t n_channels, hipStream_t st) {
+  if (a.ngen_launch <= 0) return QI_OK;
+  return launch_pass1_cfg<double, Cfg<double, 8>>(a, kind, n_channels, st);
 }
 
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
@@ -942,22 +949,31 @@ int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_chann
   return launch_forward_cfg<Cfg<float, 16>>(a, Xout, n_channels, st);
 }
 
-template <class C>
-static int launch_pass2_cfg(const RowArgs<float>& a, int kind, int nchunk, int64_t n_channels, hipStream_t st) {
+template <typename T, class C>
+static int launch_pass2_cfg(const RowArgs<T>& a, int kind, int nchunk, int64_t n_channels, hipStream_t st) {
   dim3 grid((unsigned)(a.N1 / C::G), (unsigned)nchunk, (unsigned)n_channels);
   switch (kind) {
-    case 0: return launch_p2<float, C, 0>(a, grid, st);
-    case 1: return launch_p2<float, C, 1>(a, grid, st);
-    default: return launch_p2<float, C, 2>(a, grid, st);
+    case 0: return launch_p2<T, C, 0>(a, grid, st);
+    case 1: return launch_p2<T, C, 1>(a, grid, st);
+    default: return launch_p2<T, C, 2>(a, grid, st);
   }
+}
+template <>
+int launch_pass2<double>(const RowArgs<double>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
+                         hipStream_t st) {
+  if (rows_per_group != 8) {
+    set_error("float64 pass 2 runs 8 rows per workgroup, got %d", rows_per_group);
+    return QI_ERR_UNSUPPORTED;
+  }
+  return launch_pass2_cfg<double, Cfg<double, 8>>(a, kind, nchunk, n_channels, st);
 }
 
 template <>
 int launch_pass2<float>(const RowArgs<float>& a, int kind, int rows_per_group, int nchunk, int64_t n_channels,
                         hipStream_t st) {
-  if (rows_per_group == 16) return launch_pass2_cfg<Cfg<float, 16>>(a, kind, nchunk, n_channels, st);
+  if (rows_per_group == 16) return launch_pass2_cfg<float, Cfg<float, 16>>(a, kind, nchunk, n_channels, st);
   // 8 rows: half the LDS image, two workgroups per CU that hide each other's barriers, but 64-byte store runs
-  if (rows_per_group == 8) return launch_pass2_cfg<Cfg<float, 8>>(a, kind, nchunk, n_channels, st);
+  if (rows_per_group == 8) return launch_pass2_cfg<float, Cfg<float, 8>>(a, kind, nchunk, n_channels, st);
   set_error("pass 2 supports 8 or 16 rows per workgroup, got %d", rows_per_group);
   return QI_ERR_UNSUPPORTED;
 }
@@ -1051,6 +1067,8 @@ template int launch_tail2<float>(const float*, float*, int, const double*, const
                                  double*, int64_t, int64_t, int64_t, const int32_t*, int64_t, int64_t, hipStream_t);
 template int launch_tail<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, const double*,
                                 const double*, double*, double*, int64_t, int64_t, int64_t, const int32_t*, hipStream_t);
+template int launch_tail<double>(const double*, double*, int64_t, int64_t, int, const double*, int64_t, const double*,
+                                 const double*, double*, double*, int64_t, int64_t, int64_t, const int32_t*, hipStream_t);
 template int launch_time_reduce<float>(const float*, float*, int64_t, int64_t, int, const float*, int64_t, hipStream_t);
 template int launch_time_reduce<double>(const double*, double*, int64_t, int64_t, int, const double*, int64_t,
                                         hipStream_t);

@@ -111,16 +111,14 @@ def chirp_complex(
     index_shift: float = 0,
     scale_base: float = scales.Slice.G2,
 ):
-    """Unit-amplitude chirp atom on the centred record axis (ref cwt_atoms.py:16-50).
+    """Unit-amplitude chirp atom on any time axis and offset (ref cwt_atoms.py:16-50).
     :return: atom, shifted time in s, normal_scaling, spectrum_scaling"""
     time_s = np.asarray(time_s, dtype=np.float64)
     n = len(time_s)
     fs = frequency_sample_rate_hz
     x = chirp_time(time_s, offset_time_s, fs)
-    if n < 2 or not np.allclose(x, np.arange(n) - 0.5 * (n - 1), rtol=0, atol=1e-6):
-        raise ValueError("chirp_complex: the GPU path evaluates atoms centred on a uniformly sampled record")
     p_re, p_im, omega, _ = _atom_tables(band_order_nth, [scale_frequency_center_hz], fs, index_shift, scale_base, "norm")
-    atom = engine.gabor_atoms(n, p_re, p_im, omega, np.ones(1)).cpu().numpy()[0]
+    atom = engine.gabor_atoms(n, p_re, p_im, omega, np.ones(1), x=x).cpu().numpy()[0]
     cycles_m, _, gamma = chirp_mqg_from_n(band_order_nth, index_shift, scale_base)
     a_norm, a_spect = chirp_amplitude(chirp_scale(cycles_m, scale_frequency_center_hz, fs), gamma, index_shift)
     return atom, x / fs, a_norm, a_spect

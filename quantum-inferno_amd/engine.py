@@ -339,12 +339,22 @@ def clear_plans():
         old.close()
 
 
-def gabor_atoms(n, p_re, p_im, omega, amp, device=None):
-    """[B, n] complex128 device tensor of time-domain atoms (qi_gabor_atoms)."""
+def gabor_atoms(n, p_re, p_im, omega, amp, device=None, x=None):
+    """[B, n] complex128 device tensor of time-domain atoms (qi_gabor_atoms); x: the sample positions [n] (float64,
+    in samples relative to the atom's centre) when they are not the centred uniform ones (qi_gabor_atoms_at)."""
     lib = _lib.require_gpu()
     dev = torch.device(device) if device is not None else default_device()
     keep = [_lib.darr(a) for a in (p_re, p_im, omega, amp)]
     out = torch.empty((len(keep[0][0]), n), dtype=torch.complex128, device=dev)
+    if x is not None:
+        xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+        with torch.cuda.device(dev):
+            _lib.check(
+                lib.qi_gabor_atoms_at(dev.index if dev.index is not None else torch.cuda.current_device(), n,
+                                      len(keep[0][0]), keep[0][1], keep[1][1], keep[2][1], keep[3][1], _lib.ptr(xd),
+                                      _lib.ptr(out), _lib.stream_ptr(dev))
+            )
+        return out
     with torch.cuda.device(dev):
         _lib.check(
             lib.qi_gabor_atoms(

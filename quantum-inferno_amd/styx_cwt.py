@@ -76,22 +76,18 @@ def wavelet_complex(
     scale_frequency_center_hz: Union[np.ndarray, float],
     frequency_sample_rate_hz: float,
 ):
-    """Unit-amplitude Gabor atom(s) on an arbitrary time axis (ref styx_cwt.py:68-110).  Only the centred,
-    uniformly sampled axis the CWT uses is evaluated on the GPU; that is what the reference's callers pass.
+    """Unit-amplitude Gabor atom(s) on an arbitrary time axis and offset (ref styx_cwt.py:68-110): evaluated on the
+    GPU at x = fs * (time_s - offset_time_s) whatever the axis is.
 
     :return: wavelet, shifted time, omega, scale, omega, amp_canonical, amp_unit_spectrum
     """
     time_s = np.asarray(time_s, dtype=np.float64)
     n = len(time_s)
     x = wavelet_time(time_s, offset_time_s, frequency_sample_rate_hz)
-    centred = np.arange(n) - 0.5 * (n - 1)
-    if n < 2 or not np.allclose(x, centred, rtol=0, atol=1e-6):
-        raise ValueError("wavelet_complex: the GPU path evaluates atoms centred on a uniformly sampled record "
-                         "(time_s = arange(n)/fs, offset = time_s[-1]/2), as wavelet_centered_4cwt passes them")
     scalar = np.isscalar(scale_frequency_center_hz)
     f_hz = np.atleast_1d(np.asarray(scale_frequency_center_hz, dtype=np.float64))
     scale, omega = scales.scale_from_frequency_hz(band_order_nth, f_hz, frequency_sample_rate_hz)
-    atoms = engine.gabor_atoms(n, 0.5 / scale ** 2, np.zeros_like(scale), omega, np.ones_like(scale)).cpu().numpy()
+    atoms = engine.gabor_atoms(n, 0.5 / scale ** 2, np.zeros_like(scale), omega, np.ones_like(scale), x=x).cpu().numpy()
     a_norm, a_spect = wavelet_amplitude(scale)
     if scalar:
         return atoms[0], x, omega[0], scale[0], omega[0], a_norm[0], a_spect[0]

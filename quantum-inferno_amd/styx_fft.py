@@ -82,6 +82,18 @@ def _stft_windowed(sig_wf, fs, window64, segment_points, overlap_points, nfft_po
     return freq_hz, time_s, engine.finish(z, was_numpy, was_1d), engine.finish(bits, was_numpy, was_1d)
 
 
+def _shrunk_segment(sig_wf, segment_points):
+    """scipy.signal.stft shortens nperseg to the record when the record is shorter, with a warning
+    (SciPy 1.15 signal/_spectral_py.py:_triage_segments); the window is then made for the shorter segment."""
+    n = sig_wf.shape[-1] if hasattr(sig_wf, "shape") else len(sig_wf)
+    if int(segment_points) > n:
+        import warnings
+
+        warnings.warn(f"nperseg = {int(segment_points)} is greater than input length  = {n}, using nperseg = {n}")
+        return n
+    return int(segment_points)
+
+
 class StftPlan:
     """stft_from_sig for batches of records of one shape with every buffer kept between calls (window on the device,
     outputs, scratch): the per-call work is the kernels alone.  Results are those of stft_from_sig (ref
@@ -147,6 +159,7 @@ def stft_complex_pow2(
         nfft_points = int(2 ** np.ceil(np.log2(segment_points)))
     if overlap_points is None:
         overlap_points = int(segment_points / 2)
+    segment_points = _shrunk_segment(sig_wf, segment_points)
     window = tukey_window_periodic(int(segment_points), alpha)
     f, t, z, _ = _stft_windowed(sig_wf, frequency_sample_rate_hz, window, segment_points, overlap_points, nfft_points)
     return f, t, z
@@ -167,6 +180,7 @@ def gtx_complex_pow2(
         overlap_points = int(segment_points / 2)
     if gaussian_sigma is None:
         gaussian_sigma = int(segment_points / 4)
+    segment_points = _shrunk_segment(sig_wf, segment_points)
     window = gaussian_window_periodic(int(segment_points), gaussian_sigma)
     f, t, z, _ = _stft_windowed(sig_wf, frequency_sample_rate_hz, window, segment_points, overlap_points, nfft_points)
     return f, t, z

@@ -83,6 +83,25 @@ def _log2_offset(x, ref=None, eps=_EPS):
     return out
 
 
+def log2_abs(x, eps=_EPS):
+    """log2(|x| + eps) of a real or complex CUDA tensor through the library (qi_log2_abs); float32 / complex64 stay
+    single precision, everything else is computed in double."""
+    lib = _lib.require_gpu()
+    cplx = x.is_complex()
+    if x.dtype not in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+        x = x.to(torch.float64)
+    x = x.contiguous()
+    rdt = torch.float32 if x.dtype in (torch.float32, torch.complex64) else torch.float64
+    out = torch.empty(x.shape, dtype=rdt, device=x.device)
+    if x.numel() == 0:
+        return out
+    src = torch.view_as_real(x) if cplx else x
+    with torch.cuda.device(x.device):
+        _lib.check(lib.qi_log2_abs(_lib.QI_F64 if rdt == torch.float64 else _lib.QI_F32, x.device.index, _lib.ptr(src),
+                                   1 if cplx else 0, _lib.ptr(out), x.numel(), float(eps), _lib.stream_ptr(x.device)))
+    return out
+
+
 def scale_log2_64(in_array):
     """log2(x + eps64) (ref tfr_info.py:65-70)."""
     p, was_numpy, nd = _as_panel(in_array)

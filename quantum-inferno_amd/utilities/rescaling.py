@@ -12,11 +12,14 @@ def to_log2_with_epsilon(x: Union[np.ndarray, float, list]) -> Union[np.ndarray,
     """log2(|x| + eps): amplitude bits, complex input allowed (ref rescaling.py:13-20)."""
     try:
         import torch
-
-        if isinstance(x, torch.Tensor):
-            return torch.log2(torch.abs(x) + float(get_epsilon()))
     except ImportError:  # pragma: no cover
-        pass
+        torch = None
+    if torch is not None and isinstance(x, torch.Tensor) and x.is_cuda:
+        from .. import tfr_info  # device tensors: the library's log2 kernel (qi_log2_abs), not a PyTorch expression
+
+        return tfr_info.log2_abs(x, float(get_epsilon()))
+    if torch is not None and isinstance(x, torch.Tensor):
+        x = x.numpy()
     return np.log2(np.abs(x) + get_epsilon())
 
 

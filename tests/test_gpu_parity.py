@@ -147,6 +147,43 @@ def test_corner_cases_vs_reference(golden, dtype):
     assert relmax(atoms, g["unit_atoms"]) <= 1e-12 and np.array_equal(amp[:, 0], g["unit_amp"])
 
 
+def test_atoms_on_any_time_axis_log2_of_tensors_and_short_records():
+    """Behind matching signatures the reference also (a) evaluates atoms on any time axis / offset (styx_cwt.py:68-110,
+    cwt_atoms.py:16-50), (b) takes log2 of anything array-like (rescaling.py:13-20), (c) lets SciPy shorten the STFT
+    segment to a shorter record (styx_fft.py:175-187)."""
+    import warnings
+    import scipy.signal
+
+    fs, order = 800.0, 6
+    t = np.sort(np.random.default_rng(3).uniform(0.0, 2.0, 777))  # irregular axis, arbitrary offset
+    f = np.array([5.0, 40.0, 123.0])
+    atoms, x, omega, scale, _, a_norm, a_spect = styx_cwt.wavelet_complex(order, t, 0.7321, f, fs)
+    xs = fs * (t - 0.7321)
+    s_ref, w_ref = orc.scale_omega(order, f, fs)
+    ref = np.exp(-0.5 * (xs[None, :] / s_ref[:, None]) ** 2) * np.exp(1j * w_ref[:, None] * xs[None, :])
+    assert np.array_equal(x, xs) and relmax(atoms, ref) <= 1e-12
+    atom, tc, an, asp = cwt_atoms.chirp_complex(3, t, 0.7321, 40.0, fs, index_shift=1.0)
+    m_q, _, gamma = orc.chirp_mqg_from_n(3, 1.0)
+    sc = m_q * fs / 40.0 / (2 * np.pi)
+    pp = (1 - 1j * gamma / np.pi) / (2 * sc ** 2)
+    assert relmax(atom, np.exp(-pp * xs ** 2) * np.exp(1j * m_q * xs / sc)) <= 1e-12
+    # log2(|x| + eps) of device tensors goes through the library's kernel
+    from quantum_inferno_amd.utilities import rescaling
+    z = torch.randn(3, 1000, dtype=torch.complex128, device="cuda")
+    assert np.allclose(rescaling.to_log2_with_epsilon(z).cpu().numpy(), np.log2(np.abs(z.cpu().numpy()) + orc.EPS64), rtol=0, atol=1e-12)
+    r32 = torch.randn(4096, dtype=torch.float32, device="cuda")
+    got = rescaling.to_log2_with_epsilon(r32)
+    assert got.dtype == torch.float32 and np.allclose(got.cpu().numpy(), np.log2(np.abs(r32.cpu().numpy()) + orc.EPS64), atol=2e-6)
+    # a record shorter than the segment: SciPy (and the reference through it) shortens the segment to the record
+    sig = np.random.default_rng(5).standard_normal(300)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        f1, t1, z1 = styx_fft.stft_complex_pow2(sig, fs, 512, overlap_points=100)
+        f0, t0, z0 = scipy.signal.stft(sig, fs, window=("tukey", 0.25), nperseg=512, noverlap=100, nfft=512, detrend="constant",
+                                       return_onesided=True, boundary="zeros", padded=True)
+    assert np.array_equal(f1, f0) and np.allclose(t1, t0, rtol=0, atol=1e-12) and relmax(z1, z0) <= 1e-10
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tfr_info_vs_reference(golden, dtype):
     g = golden("small_n1024.npz")
@@ -458,6 +495,60 @@ def test_native_engine_batches_match_single_records():
     assert relmax(c_nat, c_ref) <= 2e-5
 
 
+@pytest.mark.parametrize("order", [3, 12])
+def test_float64_native_engine_vs_oracle(order):
+    """float64 records of 2^20 samples run on the native two-pass kernels in double arithmetic (the exact algorithm: no
+    truncated atoms, no interpolation).  Against the oracle (pinned to the reference at this length by
+    tests/test_oracle_golden.py::test_benchmark_length_rows) on a sample of bands of every kind, at the float64
+    tolerance; every band and every fused reduction against the hipFFT engine (the reference's algorithm on the GPU)."""
+    from quantum_inferno_amd import _lib
+
+    n, fs = 1 << 20, 1000.0
+    tol = TOL[np.float64]
+    x = orc.synth_chirp(n, fs, dtype=np.float64)
+    xt = torch.from_numpy(x).cuda().unsqueeze(0)
+    f = scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
+    nb = len(f)
+    ws = engine.TfrPlan.workspace_for(n, nb, np.float64, 1)
+    nat = engine.TfrPlan(n, np.float64, None, ws, _lib.QI_ENGINE_NATIVE)
+    ref = engine.TfrPlan(n, np.float64, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        plan.set_styx_bank(order, fs)
+        plan.set_stx_bands(order, fs)
+    assert nat.stage_bands("pass2")[0] == nb and nat.stage_bands("pass2")[2] == nb  # every band on the two-pass kernels
+    pick = sorted({0, 1, nb // 5, nb // 2, (3 * nb) // 4, nb - 2, nb - 1})
+    for name, fn in (("cwt", orc.cwt_fft), ("stx", orc.stx_fft)):
+        a = getattr(nat, name)(xt, coef=True, bits=True, reductions=True)
+        _, _, want = fn(order, x, fs, bands=pick)
+        got = a.coef[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        scale = float(a.coef.abs().max())
+        assert np.max(np.abs(got - want)) <= tol["coef"] * scale, (name, order)
+        for i, j in enumerate(pick):  # each sampled band also to its own maximum (weak bands carry the rounding of the strong ones)
+            assert np.max(np.abs(got[i] - want[i])) <= 5e-9 * np.max(np.abs(want[i])), (name, order, j)
+        # (at 2^20 samples the float64 transforms carry ~2e-12 of the panel maximum: the bits are compared where that is
+        # below the 1e-8 tolerance, |z| >= 1e-3 of the maximum)
+        check_bits(a.bits[0][torch.tensor(pick, device="cuda")].cpu().numpy(), want, dict(bits=tol["bits"], bits_floor=1e-3))
+        b = getattr(ref, name)(xt, coef=True, reductions=True)
+        worst = float((a.coef - b.coef).abs().amax(dim=2).max()) / scale
+        assert worst <= tol["coef"], (name, order, worst)
+        assert torch.allclose(a.power_band, b.power_band, rtol=1e-9, atol=1e-12 * float(b.power_band.max()))
+        assert torch.allclose(a.power_time, b.power_time, rtol=1e-8, atol=1e-11 * float(b.power_time.max()))
+        assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-9)
+        lean = getattr(nat, name)(xt[:, :], coef=False, reductions=True)
+        assert torch.equal(lean.reduced, a.reduced)
+        del a, b, lean
+    # a batch of three records (tiles of the scratch) equals the single-record runs
+    xb = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 3, np.float64) for c in range(3)])).cuda()
+    if order == 3:
+        batch = nat.cwt(xb, coef=True, reductions=True)
+        for c in range(3):
+            one = nat.cwt(xb[c : c + 1], coef=True, reductions=True)
+            assert torch.equal(one.coef[0], batch.coef[c]) and torch.equal(one.power_band[0], batch.power_band[c])
+            assert torch.allclose(one.stats[0], batch.stats[c], rtol=1e-12)
+    nat.close()
+    ref.close()
+
+
 def test_streaming_chunks_float64():
     """Config-5 shape in miniature: a long float64 record as overlapped chunks; every chunk's reduced product equals
     the transform of that chunk alone, and a run restarted at a chunk boundary reproduces the rest."""
@@ -480,6 +571,46 @@ def test_streaming_chunks_float64():
     assert sorted(resumed) == [k for k in sorted(seen) if k >= 3]
     for i, band in resumed.items():
         assert torch.equal(band, seen[i][1])
+    plan.close()
+
+
+def test_stream_pipeline_full_chunks_float64():
+    """Config 5 at its real chunk length: float64 records on the host, chunks of 2^20 samples with a hop of 2^19 (three
+    hops and the flush chunk), moved through the double-buffered pipeline (pinned staging, copy stream) in channel
+    blocks; every item's reduced product equals the same chunk handed to the plan directly; two ranks' shares make
+    up the whole; a run restarted at an item reproduces the rest."""
+    from quantum_inferno_amd import stream
+
+    n, hop, fs, order = 1 << 20, 1 << 19, 800.0, 3
+    rng = np.random.default_rng(19)
+    total = n + 2 * hop + 777
+    host = np.stack([orc.synth_chirp(total, fs, c, 3, np.float64) for c in range(3)]) + 0.01 * rng.standard_normal((3, total))
+    plan = _plan_with_all(n, fs, order, np.float64, channels=2)
+    pipe = stream.StreamPipeline(plan, host, hop, block=2, transforms=("cwt", "stx"))
+    assert len(pipe.items) == 2 * 4 and [it[3] for it in pipe.items[:4]] == [0, hop, 2 * hop, total - n]
+    got = list(pipe.run())
+    assert [g.index for g in got] == list(range(8))
+    for g in got:
+        x = torch.from_numpy(host[g.first_channel : g.first_channel + g.channels, g.start : g.start + n]).cuda()
+        ref_c, ref_s = plan.cwt_stx(x, coef=False, reductions=True)
+        for mine, ref in ((g.cwt, ref_c), (g.stx, ref_s)):
+            assert torch.equal(mine.power_band, ref.power_band) and torch.equal(mine.stats, ref.stats)
+            assert torch.equal(mine.power_time, ref.power_time)
+    # against the oracle for one item (chunk 1 of channel 2, a few bands)
+    g = got[5]
+    assert (g.first_channel, g.chunk) == (2, 1)
+    pick = [0, 20, 47]
+    _, _, want = orc.cwt_fft(order, host[2, g.start : g.start + n], fs, bands=pick)
+    assert np.allclose(g.cwt.power_band[0, pick].cpu().numpy(), (np.abs(want) ** 2).sum(axis=1), rtol=1e-9)
+    # two ranks: contiguous shares of the item list; a restarted run
+    a = [(i.first_channel, i.chunk) for i in pipe.run(rank=0, world=2)]
+    b = [(i.first_channel, i.chunk) for i in pipe.run(rank=1, world=2)]
+    assert a + b == [(i.first_channel, i.chunk) for i in got] and len(a) == 4
+    again = list(pipe.run(first_item=6))
+    assert [i.index for i in again] == [6, 7] and torch.equal(again[1].stx.power_band, got[7].stx.power_band)
+    lean = stream.StreamPipeline(plan, host, hop, block=3, transforms=("stx",), keep_time=False)
+    first = next(iter(lean.run()))
+    assert first.cwt is None and first.stx.power_time is None and first.stx.power_band.shape == (3, 48)
     plan.close()
 
 
