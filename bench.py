@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU leg (0: min(16, cores))")
     ap.add_argument("--engine", default="auto", choices=["auto", "hipfft", "native"])
     ap.add_argument("--workspace-gib", type=float, default=0.0, help="plan scratch (0: sized from the batch, <= 48 GiB)")
+    ap.add_argument("--stub", type=int, default=0,
+                    help="1: CPU rehearsal of the multi-rank plumbing (gloo, no GPU): the transforms are replaced by a stub that "
+                         "writes rank- and step-dependent reduced products; everything else -- sharding, message buffers, the "
+                         "pipelined gather, the barriers and the max-over-ranks timing, the JSON line -- is the real code")
+    ap.add_argument("--stub-dump", default="", help="with --stub: rank 0 saves the last gathered buffers here (torch.save)")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     for k, v in cfg.items():
@@ -244,6 +249,50 @@ def stream_bench(args, world, rank, local, cpu):
         dist.destroy_process_group()
 
 
+class StubPlan:
+    """Stand-in for TfrPlan in --stub runs: no kernel, deterministic reduced products on the CPU."""
+
+    def __init__(self, n, n_b, rank):
+        self.n, self.n_b, self.rank, self.calls = n, n_b, rank, 0
+
+    def cwt_stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
+        import torch
+        from quantum_inferno_amd import dist as qdist
+        from quantum_inferno_amd.engine import TfrResult
+
+        n_ch = sig.shape[0]
+        if out is None:
+            out = []
+            for k in range(2):
+                r = TfrResult(frequency_hz=np.arange(self.n_b))
+                r.reduced = reduced_out[k] if reduced_out else torch.empty(qdist.reduced_slots(n_ch, self.n_b, self.n, sig.dtype), dtype=torch.float64)
+                o1 = r.reduced.numel() - n_ch * (self.n_b + 4)
+                o2 = o1 + n_ch * self.n_b
+                r.power_time = r.reduced[:o1].view(sig.dtype)[: n_ch * self.n].view(n_ch, self.n)
+                r.power_band = r.reduced[o1:o2].view(n_ch, self.n_b)
+                r.stats = r.reduced[o2:].view(n_ch, 4)
+                out.append(r)
+            out = tuple(out)
+        for k, r in enumerate(out):  # values that name the rank, the transform and the call
+            r.power_band.fill_(1000.0 * self.rank + 100.0 * k + self.calls)
+            r.power_time.fill_(float(self.rank + k))
+            r.stats.fill_(float(self.calls))
+        self.calls += 1
+        return out
+
+    def profile(self, *a, **k):
+        pass
+
+    def profile_read(self):
+        return {"zoom": (1.0, 3), "block": (0.5, 3)}
+
+    def stage_bands(self, stage):
+        return [self.n_b // 2, 0, self.n_b // 2]
+
+    def close(self):
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,11 +306,20 @@ def main():
     import torch
     import torch.distributed as dist
 
+    stub = bool(args.stub)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if stub:
+        dev = torch.device("cpu")
+        device_sync = lambda: None  # noqa: E731
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        device_sync = torch.cuda.synchronize
 
     import quantum_inferno_amd as qi
     from quantum_inferno_amd import _lib, dist as qdist, styx_fft, synth
@@ -277,11 +335,16 @@ def main():
     n_b = len(bands)
     engine_code = {"auto": _lib.QI_ENGINE_AUTO, "hipfft": _lib.QI_ENGINE_HIPFFT, "native": _lib.QI_ENGINE_NATIVE}[args.engine]
     ws = int(args.workspace_gib * 2 ** 30) if args.workspace_gib > 0 else qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=48 << 30)
-    plan = qi.TfrPlan(n, tdtype, dev, ws, engine_code)
-    plan.set_styx_bank(order, fs)
-    plan.set_stx_bands(order, fs)
-    sig = torch.from_numpy(synth.channels(n, fs, first, n_ch, total_ch, np.float32 if tdtype == torch.float32 else np.float64)).to(dev)
-    stft = styx_fft.StftPlan(n, n_ch, fs, order, tdtype, dev) if args.stft else None
+    if stub:
+        plan = StubPlan(n, n_b, rank)
+        sig = torch.zeros((n_ch, n), dtype=tdtype)
+        stft = None
+    else:
+        plan = qi.TfrPlan(n, tdtype, dev, ws, engine_code)
+        plan.set_styx_bank(order, fs)
+        plan.set_stx_bands(order, fs)
+        sig = torch.from_numpy(synth.channels(n, fs, first, n_ch, total_ch, np.float32 if tdtype == torch.float32 else np.float64)).to(dev)
+        stft = styx_fft.StftPlan(n, n_ch, fs, order, tdtype, dev) if args.stft else None
 
     # the reduced products of both transforms live in one buffer: the message of the gather, no packing copy.  With more
     # than one rank the gather of step k overlaps the transforms of step k + 1 (two sets of outputs, used in turn); the
@@ -292,10 +355,10 @@ def main():
     outs = [plan.cwt_stx(sig, coef=True, reductions=True, reduced_out=(messages[0][:slots], messages[0][slots:]))]
     for m in messages[1:]:  # further message buffers share the panels of the first set
         oc, os_ = plan.cwt_stx(sig, coef=False, reductions=True, reduced_out=(m[:slots], m[slots:]))
-        oc.coef, os_.coef = outs[0][0].coef, outs[0][1].coef
+        oc.coef, os_.coef = outs[0][0].coef, outs[0][1].coef  # (None in a --stub run)
         outs.append((oc, os_))
     pipe = qdist.GatherPipeline(depth=depth, dst=0)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if not stub else None
     stft_ms = []
 
     def step(time_stft=False):
@@ -313,16 +376,18 @@ def main():
             plan.cwt_stx(sig, out=outs[i])
             msg = pipe.submit(i, qdist.pack_reduced(list(outs[i])))
         if time_stft and stft is not None:
-            torch.cuda.synchronize()
+            device_sync()
             stft_ms.append(ev[0].elapsed_time(ev[1]))
         return msg
 
+    last_gathered = []
+
     def fence():
-        pipe.drain()
-        torch.cuda.synchronize()
+        last_gathered[:] = pipe.drain()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     t_warm = time.perf_counter()
     for _ in range(args.warmup):
@@ -330,7 +395,7 @@ def main():
     # a step of config 1 is a third of a millisecond: a few warmup steps end long before the clocks have left idle
     settle_steps = 0
     while True:
-        torch.cuda.synchronize()
+        device_sync()
         done = (time.perf_counter() - t_warm) * 1e3 >= args.settle_ms
         if world > 1:  # every rank runs the same number of steps (each step ends in a collective)
             flag = torch.tensor([1.0 if done else 0.0], device=dev)
@@ -345,7 +410,7 @@ def main():
     plan.profile(True)
     for _ in range(3):
         step(time_stft=True)
-    torch.cuda.synchronize()
+    device_sync()
     stage_all = plan.profile_read()
     dominant = max(stage_all.items(), key=lambda kv: kv[1][0])[0]
     # timed region: HIP events around the dominant stage's launches only, on every 7th transform call (odd, so that the
@@ -460,6 +525,11 @@ def main():
             line["stft"] = stft_info
         if cpu:
             line["cpu_baseline"] = cpu
+        if stub:
+            line["data"] = "stub (CPU rehearsal of the rank plumbing, no transform ran)"
+            if args.stub_dump:
+                gathered = [g.clone() if g is not None else None for g in last_gathered] if world > 1 else [qdist.pack_reduced(list(outs[0])).unsqueeze(0)]
+                torch.save({"gathered": gathered, "slots": slots, "n_ch": n_ch, "n_b": n_b, "n": n, "calls": plan.calls}, args.stub_dump)
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:

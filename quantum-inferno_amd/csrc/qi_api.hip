@@ -17,6 +17,13 @@ namespace qi {
 
 static thread_local char g_err[512] = "";
 
+// Development switches (QI_NATIVE_*, QI_STFT_FUSED: engine ablations and launch-geometry experiments)
+// are read only when QI_TUNE is set in the environment: a production process never consults them.
+const char* tune_env(const char* name) {
+  static const bool on = std::getenv("QI_TUNE") != nullptr;
+  return on ? std::getenv(name) : nullptr;
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -536,7 +543,7 @@ bool native_wanted(const qi_plan* p, int kind) {
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
 int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::BandDesc> bands) {
   auto& t = p->nat[kind];
-  if (getenv("QI_NATIVE_VERBOSE"))
+  if (tune_env("QI_NATIVE_VERBOSE"))
     for (const auto& d : bands)
       fprintf(stderr, "[qi plan] table %d (Lf = %lld) band %d: %s, support [%d, +%d)\n", kind, (long long)Lf, d.out_band,
               d.mode == 0 ? "one-pass loader" : (d.mode == 1 ? "two-pass" : "zoom"), d.k_lo, d.k_len);
@@ -799,7 +806,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
       const int32_t nchunk = (int32_t)ceil_div(count, per_wg);
       const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
-      if (getenv("QI_NATIVE_VERBOSE"))
+      if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
                 256 * wqs[g], count,
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.analytic != 0; }),
@@ -1032,7 +1039,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
       QI_TRY(analyse_support(p, 0, L, B, j, 1, d_par, &part, st, (double)se));
       const int64_t tlo = (int64_t)part[1], thi = (int64_t)part[2];
       const int64_t tlen = thi >= tlo ? thi - tlo + 1 : 0;
-      if (getenv("QI_NATIVE_VERBOSE"))
+      if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] band %d: support %lld bins as the reference cuts it, %lld bins tapered over %lld samples\n",
                 j, (long long)len, (long long)tlen, (long long)se);
       if (zoom_class(p, bank, L, tlen) < 0) continue;
@@ -1318,7 +1325,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       zoom_stats += (int64_t)znchunk[g] * zgroups[g];
       if (zgroups[g] > zslots) zslots = zgroups[g];
     }
-    if (getenv("QI_NATIVE_VERBOSE"))
+    if (tune_env("QI_NATIVE_VERBOSE"))
       fprintf(stderr, "[qi run] zoom launch of table %d: bands per level %d %d %d %d %d in rows %d %d %d %d %d\n", kind,
               zt.zoom_count[0], zt.zoom_count[1], zt.zoom_count[2], zt.zoom_count[3], zt.zoom_count[4], znchunk[0],
               znchunk[1], znchunk[2], znchunk[3], znchunk[4]);
@@ -1885,7 +1892,7 @@ int stft_impl(int device, const void* sig, int64_t C, int64_t n, const void* win
                      int64_t nfft, double scale, void* Z, void* bits, double eps, char* scratch, hipStream_t st) {
   const int64_t nseg = qi_stft_segments(n, seg, hop);
   const int64_t nf = nfft / 2 + 1;
-  static const bool fused_off = getenv("QI_STFT_FUSED") && atoi(getenv("QI_STFT_FUSED")) == 0;
+  static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
   if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft))  // one kernel: segments, transform and store from LDS
     return launch_stft_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<cplx<T>*>(Z),
                                 static_cast<T*>(bits), C, n, seg, hop, nfft, nseg, seg / 2, scale,
@@ -2007,51 +2014,51 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   // scipy.signal.fftconvolve pads to next_fast_len(2n-1) (= 2n when n = 2^k); any L >= 2n-1 gives the
   // same linear correlation, so other n use the next power of two.
   p->L = is_pow2(desc->n) ? 2 * desc->n : next_pow2(2 * desc->n - 1);
-  if (const char* e = getenv("QI_NATIVE_KMAX")) {
+  if (const char* e = tune_env("QI_NATIVE_KMAX")) {
     const long v = atol(e);
     if (v >= 0) p->native_kmax = v;
   }
   if (p->native_kmax > (int64_t)native::kMaxPrunedTerms * native::kN2)
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
-  if (const char* e = getenv("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_GROUP")) p->native_group = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_WGS")) p->native_wgs = atoi(e) > 0 ? atoi(e) : 256;
-  if (const char* e = getenv("QI_NATIVE_FWD")) p->native_fwd = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_GROUP")) p->native_group = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_WGS")) p->native_wgs = atoi(e) > 0 ? atoi(e) : 256;
+  if (const char* e = tune_env("QI_NATIVE_FWD")) p->native_fwd = atoi(e);
 #ifdef QI_NATIVE_STAMPS
-  if (getenv("QI_NATIVE_STAMPS")) {
+  if (tune_env("QI_NATIVE_STAMPS")) {
     if (hipMalloc((void**)&p->stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->stamps = nullptr;
     if (p->stamps) (void)hipMemset(p->stamps, 0, 65536 * 8 * sizeof(unsigned long long));
     if (hipMalloc((void**)&p->blk_stamps, 65536 * 8 * sizeof(unsigned long long)) != hipSuccess) p->blk_stamps = nullptr;
     if (p->blk_stamps) (void)hipMemset(p->blk_stamps, 0, 65536 * 8 * sizeof(unsigned long long));
   }
 #endif
-  if (const char* e = getenv("QI_NATIVE_SHORT")) p->native_short = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM_WGS_JOINT")) p->native_zoom_wgs_joint = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
-  if (const char* e = getenv("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_PAIR")) p->native_pair = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_GATHER_FUSED")) p->native_gather_fused = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
-  if (const char* e = getenv("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_TILE")) p->native_tile = atoll(e);
-  if (const char* e = getenv("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
-  if (const char* e = getenv("QI_NATIVE_BLK_BANDS_BATCH")) p->native_blk_bands_batch = atoi(e) > 0 ? atoi(e) : p->native_blk_bands_batch;
-  if (const char* e = getenv("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
-  if (const char* e = getenv("QI_NATIVE_ROWS")) {
+  if (const char* e = tune_env("QI_NATIVE_SHORT")) p->native_short = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS_JOINT")) p->native_zoom_wgs_joint = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
+  if (const char* e = tune_env("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_PAIR")) p->native_pair = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_GATHER_FUSED")) p->native_gather_fused = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
+  if (const char* e = tune_env("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_TILE")) p->native_tile = atoll(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
+  if (const char* e = tune_env("QI_NATIVE_BLK_BANDS_BATCH")) p->native_blk_bands_batch = atoi(e) > 0 ? atoi(e) : p->native_blk_bands_batch;
+  if (const char* e = tune_env("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
   }
-  if (const char* e = getenv("QI_NATIVE_F64")) p->native_f64 = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_F64")) p->native_f64 = atoi(e);
   if (desc->dtype == QI_F64) {  // exact paths only: every band on the two-pass kernels, evaluated at the full length
     p->native_zoom = p->native_block = p->native_short = p->native_split = 0;
     p->native_rows = 8;

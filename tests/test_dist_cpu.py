@@ -123,3 +123,41 @@ def test_single_process_gather_is_identity():
 
     flat = torch.arange(10, dtype=torch.float64)
     assert torch.equal(qdist.gather_reduced(flat)[0], flat)
+
+
+def test_bench_rank_plumbing_world2(tmp_path):
+    """bench.py itself under `torch.distributed.run` with two gloo ranks and stub transforms (--stub 1): the sharding, the
+    message buffers, the two-deep pipelined gather, the settle / barrier logic, the max-over-ranks timing and the JSON line
+    are the real code; rank 0's last gathered buffers hold every rank's reduced products of the last two steps."""
+    import json
+    import subprocess
+
+    from quantum_inferno_amd import dist as qdist
+
+    dump = os.path.join(str(tmp_path), "stub.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--stub", "1", "--log2n", "12", "--channels", "3", "--settle-ms", "0", "--stub-dump", dump]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and len(line["config"]["rank_seconds"]) == 2
+    assert line["steps"] == 6 and line["scaling"] == "weak" and line["config"]["channels_per_gpu"] == 3
+    assert line["config"]["points_per_step"] == 2 * 6 * line["config"]["bands"] * 4096  # whole job: both ranks' channels
+    assert abs(line["ms_per_step"] - max(line["config"]["rank_seconds"]) / 6 * 1e3) < 1e-3  # max over ranks
+    got = torch.load(dump)
+    n_ch, n_b, n, calls = got["n_ch"], got["n_b"], got["n"], got["calls"]
+    assert calls == 2 + 2 + 3 + 6  # two set-up calls, warmup, the profiled steps, the timed steps
+    for buf in got["gathered"]:
+        assert buf.shape == (2, 2 * got["slots"])
+    seen = set()
+    for buf in got["gathered"]:
+        for rank in range(2):
+            parts = qdist.unpack_reduced(buf[rank], n_ch, [(n_b, n), (n_b, n)], torch.float32)
+            call = int(parts[0][2][0, 0])
+            seen.add(call)
+            for k, (band, time, stats) in enumerate(parts):
+                assert torch.all(band == 1000.0 * rank + 100.0 * k + call) and torch.all(stats == call)
+                assert torch.all(time == float(rank + k))
+    assert seen == {calls - 2, calls - 1}

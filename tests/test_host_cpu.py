@@ -150,3 +150,23 @@ def test_sliding_stft_geometry_matches_scipy():
         for n in (seg, seg + 1, 3 * seg + 7, 4096, 10007):
             assert obj.p_max(n) == ref.p_max(n) and obj.k_max(n) == ref.k_max(n), (seg, overlap, n)
         np.testing.assert_array_equal(obj.dual_win, ref.dual_win)
+
+
+def test_stream_work_items_and_rank_shares():
+    """Config 5's work list: (channel block, chunk) items of the 24 h x 1024-channel job, dealt to 8 ranks in contiguous
+    shares that cover every item exactly once (no GPU needed: pure index arithmetic)."""
+    from quantum_inferno_amd import stream
+
+    items = stream.work_items(1024, 16, 69_120_000, 1 << 20, 1 << 19)
+    starts = stream.chunk_starts(69_120_000, 1 << 20, 1 << 19)
+    assert len(starts) == 131 and len(items) == 64 * 131
+    assert items[0] == (0, 16, 0, 0) and items[131] == (16, 16, 0, 0) and items[130][3] == 69_120_000 - (1 << 20)
+    seen = []
+    for r in range(8):
+        share = stream.rank_items(items, r, 8)
+        assert len(share) == 8 * 131  # eight blocks of 16 channels per GPU = its 128 channels
+        seen += share
+    assert seen == items
+    ragged = stream.work_items(5, 2, 3000, 1024, 512)
+    assert [it[:2] for it in ragged[::len(stream.chunk_starts(3000, 1024, 512))]] == [(0, 2), (2, 2), (4, 1)]
+    assert sum(len(stream.rank_items(ragged, r, 3)) for r in range(3)) == len(ragged)

@@ -3,7 +3,7 @@
 for rep in 1 2; do
   for cfg in "$@"; do
     echo -n "[$cfg] "
-    env $cfg python bench.py --cpu-seconds 0 --steps 500 --warmup 100 2> /dev/null | python -c "
+    env QI_TUNE=1 $cfg python bench.py --cpu-seconds 0 --steps 500 --warmup 100 2> /dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])" || exit 1

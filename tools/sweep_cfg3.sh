@@ -1,8 +1,8 @@
-run() { echo -n "[$*] "; env "$@" python bench.py --config 2 --channels 16 --cpu-seconds 0 --steps 10 --warmup 2 2>/dev/null | python -c "
+run() { echo -n "[$*] "; env QI_TUNE=1 "$@" python bench.py --config 2 --channels 16 --cpu-seconds 0 --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'], d['stft'])"; }
-run1() { echo -n "[cfg1 $*] "; env "$@" python bench.py --cpu-seconds 0 --steps 300 --warmup 50 2>/dev/null | python -c "
+run1() { echo -n "[cfg1 $*] "; env QI_TUNE=1 "$@" python bench.py --cpu-seconds 0 --steps 300 --warmup 50 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
