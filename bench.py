@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU leg (0: min(16, cores))")
     ap.add_argument("--engine", default="auto", choices=["auto", "hipfft", "native"])
     ap.add_argument("--workspace-gib", type=float, default=0.0, help="plan scratch (0: sized from the batch, <= 48 GiB)")
+    ap.add_argument("--wrappers", type=int, default=1,
+                    help="1: also time the reference-signature wrappers NumPy in -> NumPy out (config 1 shape, one GPU)")
     ap.add_argument("--stub", type=int, default=0,
                     help="1: CPU rehearsal of the multi-rank plumbing (gloo, no GPU): the transforms are replaced by a stub that "
                          "writes rank- and step-dependent reduced products; everything else -- sharding, message buffers, the "
@@ -523,6 +525,27 @@ def main():
         }
         if stft_info:
             line["stft"] = stft_info
+        if world == 1 and not stub and args.wrappers and n_ch == 1:
+            # the drop-in call as the tutorials make it (s04_tone_tfr.py:84-99): NumPy in, NumPy out, one transform per
+            # call -- host <-> device copies and the widening to the reference's complex128 included (never `value`)
+            from quantum_inferno_amd import engine as qengine, styx_cwt, styx_stx
+
+            x_host = sig[0].cpu().numpy()
+            out_w = {}
+            for mode in ("reference", "native"):
+                qengine.NUMPY_RESULT_DTYPE = mode
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    tw0 = time.perf_counter()
+                    c_np = styx_cwt.cwt_complex_any_scale_pow2(order, x_host, fs)[2]
+                    s_np = styx_stx.stx_complex_any_scale_pow2(order, x_host, fs)[2]
+                    tw = time.perf_counter() - tw0
+                out_w[mode] = {"ms": round(tw * 1e3, 2), "mpoints_per_s": round(2 * n_b * n / tw / 1e6, 1),
+                               "result_dtype": str(c_np.dtype), "host_bytes": int(c_np.nbytes + s_np.nbytes)}
+                del c_np, s_np
+            qengine.NUMPY_RESULT_DTYPE = "reference"
+            qengine.clear_plans()
+            line["numpy_wrappers"] = out_w
         if cpu:
             line["cpu_baseline"] = cpu
         if stub:

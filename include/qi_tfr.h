@@ -197,6 +197,11 @@ int64_t qi_power_marginals_scratch_bytes(int64_t n_channels, int64_t n_bands, in
 int qi_log2_offset(int dtype, int device, const void* in, void* out, int64_t n_channels, int64_t count, double eps,
                    const void* ref, qi_stream stream);
 
+/* out[i] = (double) in[i] for `count` float32 values (a complex64 panel is 2 * count floats): the reference returns
+ * complex128 panels / float64 bits whatever the record's dtype (styx_cwt.py:195-198, styx_stx.py:228, cwt_atoms.py:408,442);
+ * the wrappers compute float32 records in float32 and widen on the device before the copy to the host. */
+int qi_widen(int device, const void* in, void* out, int64_t count, qi_stream stream);
+
 /* out[i] = log2(|in[i]| + eps) for `count` real (is_complex = 0) or complex (1; dtype is the real type) values:
  * utilities.rescaling.to_log2_with_epsilon (utilities/rescaling.py:13-20) on a device array. */
 int qi_log2_abs(int dtype, int device, const void* in, int is_complex, void* out, int64_t count, double eps,

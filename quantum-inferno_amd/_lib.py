@@ -72,6 +72,7 @@ PROTOTYPES = {
     "qi_power_marginals": (_int, [_int, _int, _P, _i64, _i64, _i64, _P, _P, _P, _P, _i64, _P]),
     "qi_power_marginals_scratch_bytes": (_i64, [_i64, _i64, _i64]),
     "qi_log2_offset": (_int, [_int, _int, _P, _P, _i64, _i64, _dbl, _P, _P]),
+    "qi_widen": (_int, [_int, _P, _P, _i64, _P]),
     "qi_log2_abs": (_int, [_int, _int, _P, _int, _P, _i64, _dbl, _P]),
     "qi_shannon_panel": (_int, [_int, _int, _P, _P, _int, _i64, _i64, _i64, _dbl, _P, _P, _P, _P, _P]),
     "qi_sliding_scratch_bytes": (_i64, [_int, _i64, _i64, _i64]),

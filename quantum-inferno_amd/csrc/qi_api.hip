@@ -1649,6 +1649,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
           QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
         }
         p->prof.end(QI_STAGE_ZOOM_COARSE, st);
+        if (pair && p->native_pair == 2) {  // the block launch has covered the coarse stage; the interpolation launch runs alone
+          QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+        }
         p->prof.begin(st, QI_STAGE_ZOOM);
         const bool joint_fine = joint && p->native_fuse > 3 && (finish->zoom.coef != nullptr) == (z.coef != nullptr) &&
                                 (finish->zoom.bits != nullptr) == (z.bits != nullptr);
@@ -2602,6 +2605,12 @@ int qi_log2_offset(int dtype, int device, const void* in, void* out, int64_t C, 
                                                       (const double*)ref, (hipStream_t)stream)
                          : launch_log2_offset<float>((const float*)in, (float*)out, C, count, (float)eps,
                                                      (const double*)ref, (hipStream_t)stream);
+}
+
+int qi_widen(int device, const void* in, void* out, int64_t count, qi_stream stream) {
+  QI_REQUIRE(in && out && count > 0, "bad argument");
+  DeviceGuard g(device);
+  return launch_widen((const float*)in, (double*)out, count, (hipStream_t)stream);
 }
 
 int qi_log2_abs(int dtype, int device, const void* in, int is_complex, void* out, int64_t count, double eps,

@@ -168,6 +168,7 @@ int launch_power_marginals(const T* P, int64_t C, int64_t B, int64_t n, T* power
                            double* part_stat, hipStream_t st);
 template <typename T>
 int launch_log2_offset(const T* in, T* out, int64_t C, int64_t count, T eps, const double* ref, hipStream_t st);
+int launch_widen(const float* in, double* out, int64_t count, hipStream_t st);
 template <typename T>
 int launch_log2_abs(const T* in, int is_complex, T* out, int64_t count, T eps, hipStream_t st);
 template <typename T>

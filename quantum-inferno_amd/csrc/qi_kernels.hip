@@ -436,6 +436,19 @@ int launch_log2_offset(const T* in, T* out, int64_t C, int64_t count, T eps, con
   return QI_OK;
 }
 
+// out[i] = (double)in[i]: float32 results handed to callers that expect the reference's float64 / complex128
+__global__ void k_widen(const float* __restrict__ in, double* __restrict__ out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+int launch_widen(const float* in, double* out, int64_t count, hipStream_t st) {
+  int64_t blocks = ceil_div(count, 256);
+  if (blocks > 16384) blocks = 16384;
+  k_widen<<<(unsigned)blocks, 256, 0, st>>>(in, out, count);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
 template <typename T>
 int launch_log2_abs(const T* in, int is_complex, T* out, int64_t count, T eps, hipStream_t st) {
   int64_t blocks = ceil_div(count, 256);

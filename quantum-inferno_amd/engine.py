@@ -382,16 +382,22 @@ NUMPY_RESULT_DTYPE = "reference"
 
 def finish(result_tensor, was_numpy, was_1d, widen=False):
     """Undo as_signal's batching / device move on an output.  widen: a panel the reference would return in double
-    precision (see NUMPY_RESULT_DTYPE)."""
+    precision (see NUMPY_RESULT_DTYPE).  NumPy callers get an array backed by page-locked memory (the copy from the
+    device then runs at PCIe speed instead of through a pageable staging buffer); the widening runs on the device."""
     if result_tensor is None:
         return None
     t = result_tensor[0] if was_1d else result_tensor
     if not was_numpy:
         return t
-    a = t.cpu().numpy()
-    if widen and NUMPY_RESULT_DTYPE == "reference":
-        if a.dtype == np.complex64:
-            a = a.astype(np.complex128)
-        elif a.dtype == np.float32:
-            a = a.astype(np.float64)
-    return a
+    t = t.contiguous()
+    if widen and NUMPY_RESULT_DTYPE == "reference" and t.dtype in (torch.complex64, torch.float32) and t.numel() > 0:
+        wide = torch.empty(t.shape, dtype=torch.complex128 if t.dtype == torch.complex64 else torch.float64, device=t.device)
+        src = torch.view_as_real(t) if t.is_complex() else t
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.load().qi_widen(t.device.index, _lib.ptr(src), _lib.ptr(wide), src.numel(), _lib.stream_ptr(t.device)))
+        t = wide
+    if t.numel() * t.element_size() >= (1 << 20):
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t)
+        return host.numpy()
+    return t.cpu().numpy()

@@ -118,13 +118,16 @@ def tfr_stx_fft(
         sa, sp = _lib.darr(sigma)
         _lib.check(plan._lib.qi_plan_set_stx_bands(plan._handle, n_b, ip, sp))
         plan.freq[_lib.QI_TABLE_STX] = frequency_stx
-        tfr = plan.stx(sig, coef=True).coef[0, :, :n_out]
-        psd = tfr.real ** 2 + tfr.imag ** 2 + float(scales.get_epsilon())
-        dev = tfr.device
-        win = torch.exp(
-            -0.5 * torch.from_numpy(sigma).to(dev)[:, None] ** 2 * torch.from_numpy(omega_fft).to(dev)[None, :] ** 2
-        ).to(torch.complex128)
+        tfr = plan.stx(sig, coef=True).coef[0, :, :n_out].contiguous()
     finally:
         plan.close()
-    conv = (lambda t: engine.finish(t, was_numpy, False, widen=True))
-    return conv(tfr.contiguous()), conv(psd), frequency_stx, frequency_stx_fft, conv(win)
+    # the two by-products the reference also returns: psd = |tfr|^2 + eps and the Gaussian windows on the FFT bins
+    # (styx_stx.py:187-192) -- host arithmetic (NumPy), handed back on the device only for tensor callers
+    win = np.exp(-0.5 * sigma[:, None] ** 2 * omega_fft[None, :] ** 2).astype(np.complex128)
+    if was_numpy:
+        tfr_np = engine.finish(tfr, True, False, widen=True)
+        psd = tfr_np.real ** 2 + tfr_np.imag ** 2 + float(scales.get_epsilon())
+        return tfr_np, psd, frequency_stx, frequency_stx_fft, win
+    # (tensor callers: the same by-product as a device expression)
+    psd = tfr.real ** 2 + tfr.imag ** 2 + float(scales.get_epsilon())
+    return tfr, psd, frequency_stx, frequency_stx_fft, torch.from_numpy(win).to(tfr.device)

@@ -795,14 +795,14 @@ def test_fused_call_other_requests_and_tiles():
     small.close()
 
 
-@pytest.mark.parametrize("log2n", [18, 19, 21, 22])
-def test_native_engine_other_lengths(log2n):
+@pytest.mark.parametrize("log2n,order", [(18, 3), (19, 3), (21, 3), (22, 3), (19, 12), (21, 12), (21, 6)])
+def test_native_engine_other_lengths(log2n, order):
     """Stockwell transform and styx CWT at the other power-of-two lengths the native engine takes (their order-3 band
     tables need only the zoom and block engines -- the CWT's longest atoms as split bands -- which are not tied to the
     two-pass kernels' 2^20 / 2^21) against the hipFFT engine: every row, the fused reductions, and the fused call."""
     from quantum_inferno_amd import _lib
 
-    n, fs, order = 1 << log2n, 1000.0, 3
+    n, fs = 1 << log2n, 1000.0
     rng = np.random.default_rng(log2n)
     x = orc.synth_chirp(n, fs, 0, 1, np.float32) + 0.25 * rng.standard_normal(n).astype(np.float32)
     x = torch.from_numpy(x[None, :]).cuda()
