@@ -47,9 +47,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
-    ap.add_argument("--settle-ms", type=float, default=250.0,
+    ap.add_argument("--settle-ms", type=float, default=3000.0,
                     help="after the warmup steps, keep stepping (untimed) until this much wall time has passed since "
-                         "their start: the GPU leaves its idle clocks only after ~0.1 s of load (0 = off)")
+                         "their start: the GPU leaves its idle clocks only after ~0.1 s of load, and a GPU phase of a few "
+                         "seconds can be seen by an outside utilisation sampler (0 = off)")
     ap.add_argument("--channels", type=int, default=None, help="records per GPU (weak scaling)")
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--order", type=float, default=None)
