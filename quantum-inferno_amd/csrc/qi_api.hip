@@ -351,9 +351,9 @@ struct qi_plan {
                            // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
                            // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
   int native_f64 = 1;      // float64 plans run the two-pass kernels (exact algorithm, double arithmetic) at 2^20 / 2^21-point transforms
-  int native_gather_fused = 4;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
-                                // (no gather launch, two passes over the coarse storage fewer: -30 % of that stage at 16 records);
-                                // below it the gather launch's 16 x more workgroups win (one record: 28 vs 43 us); 0: never
+  int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
+                                // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen
+                                // inputs batched: -35 % of that stage at 16 records, -20 % at one); 0: never
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // split bands of the styx bank (atoms longer than the record): zoom engine + edge pieces, see split_taper

@@ -704,8 +704,7 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
   const int64_t ch = blockIdx.z;
   const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);
   cplx<T> v[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) v[b] = zoom_gather_value<T, STX>(a, bd, tau1, col + 256 * b, X);
+  zoom_gather16<T, STX>(a, bd, tau1, col, X, v);
   {
     float s, c;
     sincospif((float)tid * (2.0f / 256.0f), &s, &c);
