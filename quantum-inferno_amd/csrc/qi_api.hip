@@ -292,7 +292,7 @@ struct qi_plan {
     int32_t* d_zoom_plane_band = nullptr;  // owner band of every coarse plane
     std::vector<std::pair<int32_t, int32_t>> h_zoom;  // (panel row, level) of the zoom bands
     std::vector<int32_t> h_rows;                      // panel rows of the pass-2 bands
-    int32_t nzoom = 0, zoom_count[native::kZoomLevels] = {0, 0, 0, 0, 0};
+    int32_t nzoom = 0, zoom_count[native::kZoomClasses] = {0, 0, 0, 0, 0, 0, 0};
     int64_t zoom_planes = 0;  // 4096-sample planes of coarse storage per record
     int zoom_max_level = 0;
     void release() {
@@ -339,11 +339,13 @@ struct qi_plan {
   bool shared_valid = false;
   int32_t* d_band_slots[3] = {nullptr, nullptr, nullptr};  // per table kind: partial slots each band's engine writes
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
+  int native_zoom_short = 1;      // bands oversampled >= 8 / >= 32 times on the coarsest grid use 6- / 4-tap interpolators
+  int native_zoom_short_from = 4; // ... in calls (tiles) of at least this many records; below, they run with the 10-tap class
   int native_zoom_max_level = 3;  // finest coarse grid the zoom engine may use (level 4 costs more in the coarse stage than two-pass saves)
   int native_zoom_waves = 2048; // native_zoom_wgs = 0: waves each level of a zoom launch should have at least
   int native_zoom_wgs_joint = 768;   // the same budget per table in the joint launch of qi_cwt_stx (512 .. 1024 measured within 1.5 %)
   int native_zoom_wgs = 0;      // > 0: workgroups of a zoom launch, dealt to the levels by work (measured: 1.5 % slower than the per-level rule)
-  float* d_zoom_w[native::kZoomLevels][2] = {};  // interpolation weights [level][lane offset]
+  float* d_zoom_w[native::kZoomClasses][2] = {};  // interpolation weights [class][lane offset]
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
   // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
   int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
@@ -439,6 +441,9 @@ int plan_tiles(const qi_plan* p, int64_t C, int64_t B, int64_t L, Tile* t) {
 }
 
 enum class Kind { Linear, Circular, Stockwell };
+
+// order of the zoom classes in a table's band list (classes 6, 5 and 0 share the coarsest grid)
+constexpr int kZoomListOrder[native::kZoomClasses] = {6, 5, 0, 1, 2, 3, 4};
 
 template <typename T>
 int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
@@ -550,19 +555,25 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
   // bands marked for the zoom engine (mode 2 + level) leave the pass-2 list, ordered by level
   {
     std::vector<native::BandDesc> rest;
-    std::vector<std::vector<native::BandDesc>> by_level(native::kZoomLevels);
+    std::vector<std::vector<native::BandDesc>> by_level(native::kZoomClasses);
     for (const auto& d : bands) {
       if (d.mode >= 2) by_level[d.mode - 2].push_back(d);
       else rest.push_back(d);
     }
-    // a level with only a few bands is not worth a launch of its own: they join the next occupied level up (at
-    // most two up: each level doubles their coarse grid and adds window samples)
+    // a class with only a few bands is not worth rows of its own in the launch: they join the next class that can carry
+    // them -- the 4-tap class the 6-tap one, the 6-tap class the 10-tap class of the same grid, a grid level the next
+    // occupied level up (at most two up: each level doubles their coarse grid and adds window samples)
+    auto join = [&](int from, int to) {
+      by_level[to].insert(by_level[to].begin(), by_level[from].begin(), by_level[from].end());
+      by_level[from].clear();
+    };
+    if (!by_level[6].empty() && by_level[6].size() < 6) join(6, 5);
+    if (!by_level[5].empty() && by_level[5].size() < 6) join(5, 0);
     for (int g = 0; g + 1 < native::kZoomLevels; ++g) {
       if (by_level[g].empty() || by_level[g].size() >= 6) continue;
       for (int h = g + 1; h <= g + 2 && h < native::kZoomLevels; ++h)
         if (!by_level[h].empty()) {
-          by_level[h].insert(by_level[h].begin(), by_level[g].begin(), by_level[g].end());
-          by_level[g].clear();
+          join(g, h);
           break;
         }
     }
@@ -570,13 +581,17 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
     t.h_zoom.clear();
     t.zoom_planes = 0;
     t.zoom_max_level = 0;
-    for (int g = 0; g < native::kZoomLevels; ++g) {
-      t.zoom_count[g] = (int32_t)by_level[g].size();
+    for (int g = 0; g < native::kZoomClasses; ++g) t.zoom_count[g] = (int32_t)by_level[g].size();
+    for (int gi = 0; gi < native::kZoomClasses; ++gi) {
+      // list order: the short-interpolator classes first, next to the 10-tap class of their grid, so that a call with
+      // few records can run all three as one class (kZoomListOrder)
+      const int g = kZoomListOrder[gi];
+      const int grid = native::zoom_grid(g);
       for (auto d : by_level[g]) {
-        d.edge_slot = g;                    // level of the band's coarse grid
+        d.edge_slot = grid;                 // level of the band's coarse grid
         d.edge = (int32_t)t.zoom_planes;    // first plane of its coarse array
-        t.zoom_planes += ((Lf / native::kZoomD) << g) / native::kBlk;
-        t.zoom_max_level = g;
+        t.zoom_planes += ((Lf / native::kZoomD) << grid) / native::kBlk;
+        if (grid > t.zoom_max_level) t.zoom_max_level = grid;
         zoom.push_back(d);
         t.h_zoom.push_back({d.out_band, g});
       }
@@ -592,9 +607,11 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       }
       QI_HIP(hipMalloc((void**)&t.d_zoom_plane_band, owner.size() * sizeof(int32_t)));
       QI_HIP(hipMemcpy(t.d_zoom_plane_band, owner.data(), owner.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-      for (int g = 0; g < native::kZoomLevels; ++g)
+      for (int g = 0; g < native::kZoomClasses; ++g)
         for (int e = 0; e < 2; ++e) {
-          if (p->d_zoom_w[g][e] || t.zoom_count[g] == 0) continue;
+          // (class 0 also serves the bands of classes 5 and 6 in calls with few records)
+          const bool needed = t.zoom_count[g] > 0 || (g == 0 && t.zoom_count[5] + t.zoom_count[6] > 0);
+          if (p->d_zoom_w[g][e] || !needed) continue;
           std::vector<float> w((size_t)64 * native::zoom_taps(g));
           native::zoom_weights(g, e, w.data());
           QI_HIP(hipMalloc((void**)&p->d_zoom_w[g][e], w.size() * sizeof(float)));
@@ -924,7 +941,15 @@ int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
   if (M0 % native::kBlk != 0 || !is_pow2(M0 / native::kBlk)) return -1;  // the coarse stage works in 4096-point planes
   for (int g = 0; g < native::kZoomLevels; ++g) {
     if (p->n % ((int64_t)native::kZoomD * native::zoom_steps(g) * 4) != 0) return -1;
-    if (native::kZoomOversample * len <= (M0 << g)) return g <= p->native_zoom_max_level ? g : -1;
+    if (native::kZoomOversample * len <= (M0 << g)) {
+      if (g > p->native_zoom_max_level) return -1;
+      // on the coarsest grid the band may be oversampled far more than 4 times: shorter interpolators (classes 5, 6)
+      if (g == 0 && p->native_zoom_short) {
+        if ((int64_t)native::zoom_design_oversampling(6) * len <= M0) return 6;
+        if ((int64_t)native::zoom_design_oversampling(5) * len <= M0) return 5;
+      }
+      return g;
+    }
   }
   return -1;
 }
@@ -1266,7 +1291,16 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // zoom engine launch (narrow bands of the main table): its chunks come last
   const auto& zt = p->nat[kind];
   const bool zoom = zt.nzoom > 0;
-  constexpr int NL = native::kZoomLevels;
+  constexpr int NL = native::kZoomClasses;
+  // per-class band counts of this call: with few records the launch cannot afford rows for every class (its workgroup
+  // budget is dealt over the rows), so the short-interpolator classes run as part of the 10-tap class of their grid
+  // (their bands are oversampled enough for any of the three interpolators)
+  int zcount[NL];
+  for (int g = 0; g < NL; ++g) zcount[g] = zt.zoom_count[g];
+  if (C < p->native_zoom_short_from) {
+    zcount[0] += zcount[5] + zcount[6];
+    zcount[5] = zcount[6] = 0;
+  }
   int znchunk[NL] = {}, zplanes = 0;
   int64_t zstat_base[NL] = {}, zgroups[NL] = {}, zoom_stats = 0, zslots = 0;
   const int chunk_z0 = chunk_total;
@@ -1275,10 +1309,10 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     // All workgroups of the launch should be resident at once (native_zoom_wgs of them) and finish together: every
     // level starts with one row, then the level whose rows carry the most work per workgroup gets the next one
     // (per band: a little more at the higher levels, half at level 3 and up where a workgroup covers half the samples).
-    const double level_cost[NL] = {1.0, 1.08, 1.25, 0.75, 1.0};
+    const double level_cost[NL] = {1.0, 1.08, 1.25, 0.75, 1.0, 0.85, 0.75};
     int64_t wgs = 0;
     for (int g = 0; g < NL; ++g) {
-      if (zt.zoom_count[g] <= 0) continue;
+      if (zcount[g] <= 0) continue;
       zgroups[g] = native::zoom_groups(n, g);
       znchunk[g] = 1;
       wgs += zgroups[g] * C;
@@ -1292,8 +1326,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         int best = -1;
         double best_load = 0.0;
         for (int g = 0; g < NL; ++g) {
-          if (zt.zoom_count[g] <= 0 || znchunk[g] >= zt.zoom_count[g]) continue;
-          const double load = level_cost[g] * (double)ceil_div(zt.zoom_count[g], znchunk[g]);
+          if (zcount[g] <= 0 || znchunk[g] >= zcount[g]) continue;
+          const double load = level_cost[g] * (double)ceil_div(zcount[g], znchunk[g]);
           if (load > best_load) {
             best_load = load;
             best = g;
@@ -1304,31 +1338,31 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         // not shorten the launch)
         bool is_max = true;
         for (int g = 0; g < NL; ++g)
-          if (zt.zoom_count[g] > 0 && level_cost[g] * (double)ceil_div(zt.zoom_count[g], znchunk[g]) > best_load) is_max = false;
+          if (zcount[g] > 0 && level_cost[g] * (double)ceil_div(zcount[g], znchunk[g]) > best_load) is_max = false;
         if (!is_max) break;
         znchunk[best] += 1;
         wgs += zgroups[best] * C;
       }
     } else {
       for (int g = 0; g < NL; ++g) {
-        if (zt.zoom_count[g] <= 0) continue;
+        if (zcount[g] <= 0) continue;
         int nc = (int)ceil_div(p->native_zoom_waves, 4 * zgroups[g] * C);
         if (nc < 1) nc = 1;
-        if (nc > zt.zoom_count[g]) nc = zt.zoom_count[g];
+        if (nc > zcount[g]) nc = zcount[g];
         znchunk[g] = nc;
       }
     }
     for (int g = 0; g < NL; ++g) {
-      if (zt.zoom_count[g] <= 0) continue;
+      if (zcount[g] <= 0) continue;
       zplanes += znchunk[g];
       zstat_base[g] = zoom_stats;
       zoom_stats += (int64_t)znchunk[g] * zgroups[g];
       if (zgroups[g] > zslots) zslots = zgroups[g];
     }
     if (tune_env("QI_NATIVE_VERBOSE"))
-      fprintf(stderr, "[qi run] zoom launch of table %d: bands per level %d %d %d %d %d in rows %d %d %d %d %d\n", kind,
-              zt.zoom_count[0], zt.zoom_count[1], zt.zoom_count[2], zt.zoom_count[3], zt.zoom_count[4], znchunk[0],
-              znchunk[1], znchunk[2], znchunk[3], znchunk[4]);
+      fprintf(stderr, "[qi run] zoom launch of table %d: bands per class %d %d %d %d %d | 6-tap %d 4-tap %d in rows %d %d %d %d %d | %d %d\n", kind,
+              zcount[0], zcount[1], zcount[2], zcount[3], zcount[4], zcount[5],
+              zcount[6], znchunk[0], znchunk[1], znchunk[2], znchunk[3], znchunk[4], znchunk[5], znchunk[6]);
     chunk_total += zplanes;
   }
   int64_t nbk = nblk_max + (shorts ? 1 : 0);          // partial slots per band (last one: edge samples)
@@ -1618,16 +1652,21 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       z.split_part = zadd;
       z.split_rows = nsplit;
-      int first = 0, chunk0 = 0;
+      int chunk0 = 0;
       for (int g = 0; g < NL; ++g) {
-        z.lvl_first[g] = first;
-        z.lvl_count[g] = zt.zoom_count[g];
+        z.lvl_count[g] = zcount[g];
         z.lvl_chunk0[g] = chunk0;
         z.lvl_nchunk[g] = znchunk[g];
         z.lvl_stat_base[g] = p2_stats + blk_stats + zstat_base[g];
         z.lvl_weights[g] = p->d_zoom_w[g][z.lane_off];
-        first += zt.zoom_count[g];
         chunk0 += znchunk[g];
+      }
+      int first = 0;
+      for (int gi = 0; gi < NL; ++gi) {  // positions in the band list (kZoomListOrder): a merged class 0 starts where class 6 does
+        const int g = kZoomListOrder[gi];
+        z.lvl_first[g] = first;
+        first += zcount[g];
+        if (g == 0 && zcount[0] != zt.zoom_count[0]) z.lvl_first[0] = 0;
       }
       if (deferring && p->native_fuse > 2) {  // the Stockwell run of qi_cwt_stx launches them with its own
         defer->zoom = z;
@@ -2039,6 +2078,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_SHORT")) p->native_zoom_short = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_ZOOM_SHORT_FROM")) p->native_zoom_short_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS_JOINT")) p->native_zoom_wgs_joint = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;

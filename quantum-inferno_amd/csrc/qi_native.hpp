@@ -165,14 +165,22 @@ int launch_block_taps_edge(double2* g, int w, int64_t n, double taper_e, const d
 // ---- zoom engine (qi_zoom.hip): narrow-spectrum bands from a coarse inverse transform + band-limited interpolation
 // A band with K occupied bins is assigned the coarsest grid "level" g on which it is oversampled >= 4 times:
 // D = 64 >> g fine samples per coarse sample, M_g = (Lf / 64) << g coarse samples, S = 1 << g coarse samples per
-// wave-step (a wave-step = 64 consecutive outputs = the 64 lanes).  The interpolator is always the 12-tap
-// Kaiser-windowed sinc (beta = 14) in coarse-sample units; a wave-step spans S coarse intervals, so its window has
-// 12 + S samples and every lane carries the 12 + S weights of its own position in it.
+// wave-step (a wave-step = 64 consecutive outputs = the 64 lanes).  The interpolator has N = 10, 6 or 4 taps in
+// coarse-sample units (by the band's oversampling, see the classes below); a wave-step spans S coarse intervals, so its
+// window has N + S samples and every lane carries the N + S weights of its own position in it.
 constexpr int kZoomD = 64;  // fine samples per coarse sample at level 0 (= the lanes of a wave)
-constexpr int kZoomLevels = 5;
-constexpr int zoom_span(int level) { return 1 << level; }                         // S
-constexpr int zoom_taps(int level) { return 12 + zoom_span(level); }               // window samples per wave-step
-constexpr int zoom_steps(int level) { return level <= 2 ? 16 : (64 >> level); }    // wave-steps per wave and band
+constexpr int kZoomLevels = 5;   // coarse-grid levels
+// A band's CLASS = (grid level, interpolator).  Classes 0..4: grid level 0..4, bands oversampled >= 4 times on their
+// grid, 10-tap interpolator.  Classes 5 and 6: grid level 0 (the coarsest grid: every narrower band lands there), bands
+// oversampled >= 8 / >= 32 times, 6- / 4-tap interpolators -- the more a band is oversampled, the shorter the
+// interpolator that reaches the same error (zoom_weights).  `level` below is a class index.
+constexpr int kZoomClasses = 7;
+constexpr int zoom_grid(int cls) { return cls < kZoomLevels ? cls : 0; }
+constexpr int zoom_ntap(int cls) { return cls < kZoomLevels ? 10 : (cls == 5 ? 6 : 4); }
+constexpr int zoom_design_oversampling(int cls) { return cls < kZoomLevels ? 4 : (cls == 5 ? 8 : 32); }
+constexpr int zoom_span(int cls) { return 1 << zoom_grid(cls); }                   // S
+constexpr int zoom_taps(int cls) { return zoom_ntap(cls) + zoom_span(cls); }       // window samples per wave-step
+constexpr int zoom_steps(int cls) { return zoom_grid(cls) <= 2 ? 16 : (64 >> zoom_grid(cls)); }  // wave-steps per wave and band
                                                                                    // (window of <= 128 coarse samples)
 constexpr int kZoomOversample = 4;
 template <typename T>
@@ -185,9 +193,9 @@ struct ZoomArgs {
   const int32_t* plane_band;       // [planes] device: band (index into `bands`) that owns each coarse plane
   // the fine launch covers every level: blockIdx.y in [lvl_chunk0[g], lvl_chunk0[g] + lvl_nchunk[g]) works on level g,
   // bands [lvl_first[g], lvl_first[g] + lvl_count[g]) of `bands`, and writes per-time plane chunk_base + blockIdx.y
-  int32_t lvl_first[kZoomLevels], lvl_count[kZoomLevels], lvl_chunk0[kZoomLevels], lvl_nchunk[kZoomLevels];
-  int64_t lvl_stat_base[kZoomLevels];
-  const float* lvl_weights[kZoomLevels];  // [taps][64] interpolation weights of the lanes, per level
+  int32_t lvl_first[kZoomClasses], lvl_count[kZoomClasses], lvl_chunk0[kZoomClasses], lvl_nchunk[kZoomClasses];
+  int64_t lvl_stat_base[kZoomClasses];
+  const float* lvl_weights[kZoomClasses];  // [taps][64] interpolation weights of the lanes, per class
   const cplx<T>* X;        // [C][Lf << x_shift] spectra of the records
   int32_t x_shift;         // 1: X is the spectrum of the records zero-padded to twice Lf (bin k of Lf = bin 2k)
   const cplx<T>* Hc;       // compact bank (Gabor kinds)

@@ -63,15 +63,16 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
   if ((int64_t)blockIdx.x >= a.n / ((int64_t)kZoomD * STEPS * NW)) return;  // this level has fewer groups along time
   const int nchunk = a.lvl_nchunk[LEVEL];
   const float* __restrict__ weights = a.lvl_weights[LEVEL];
-  constexpr int HALF = 6, WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
+  constexpr int GRID = zoom_grid(LEVEL), HALF = zoom_ntap(LEVEL) / 2;
+  constexpr int WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
   static_assert(WIN <= 2 * kWave, "the window of one wave must fit two registers of its lanes");
   constexpr bool TWO = WIN > kWave;  // the window spills into a second vector register
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int64_t ch = blockIdx.z;
   const int64_t gw = (int64_t)blockIdx.x * NW + wv;  // wave index along time
   const uint32_t step_a = (uint32_t)gw * STEPS;      // first wave-step of this wave
-  const uint32_t mmask = (uint32_t)((a.Lf / kZoomD) << LEVEL) - 1u, lmask = (uint32_t)a.Lf - 1u;
-  const int plog2 = ilog2((int)((a.Lf / kZoomD) / kBlk)) + LEVEL;  // log2 of the planes per band
+  const uint32_t mmask = (uint32_t)((a.Lf / kZoomD) << GRID) - 1u, lmask = (uint32_t)a.Lf - 1u;
+  const int plog2 = ilog2((int)((a.Lf / kZoomD) / kBlk)) + GRID;  // log2 of the planes per band
   float wgt[TAPS];
 #pragma unroll
   for (int j = 0; j < TAPS; ++j) wgt[j] = weights[j * kWave + lane];  // [tap][lane]: coalesced
@@ -229,7 +230,9 @@ __device__ __forceinline__ void zoom_row(const ZoomArgs<T>& a, int y, double (*s
   else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[1], y, s_red, s_fin);
   else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[2], y, s_red, s_fin);
   else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[3], y, s_red, s_fin);
-  else zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[4] + a.lvl_nchunk[4]) zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[5] + a.lvl_nchunk[5]) zoom_level<T, 5, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[5], y, s_red, s_fin);
+  else zoom_level<T, 6, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[6], y, s_red, s_fin);
 }
 
 // one launch for every level: blockIdx.y is the row
@@ -293,7 +296,7 @@ int launch_zoom_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>&
 static int zoom_grid(const ZoomArgs<float>& a, int64_t* groups_out, int* rows_out) {
   int64_t groups = 0;
   int chunks = 0;
-  for (int g = 0; g < kZoomLevels; ++g) {
+  for (int g = 0; g < kZoomClasses; ++g) {
     if (a.lvl_nchunk[g] <= 0) continue;
     const int64_t gg = zoom_groups(a.n, g);
     if (gg < 1 || gg * kZoomD * zoom_steps(g) * (kZoomThreads / kWave) != a.n) {
@@ -339,34 +342,53 @@ int launch_zoom2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, in
   return QI_OK;
 }
 
-// Interpolation weights of lane L for window sample j of a wave-step at `level`: the lane sits x = (L - e) / D coarse
-// samples after the window's reference sample (index 6), D = 64 >> level; weight = h((j - 6) - x), h = 12-tap
-// Kaiser-windowed sinc (beta = 14), zero outside |.| < 6.  Layout [tap][lane].
-void zoom_weights(int level, int lane_off, float* w) {
-  const int taps = zoom_taps(level);
-  const double beta = 14.0, half = 6.0, D = (double)(kZoomD >> level);
-  auto bessel_i0 = [](double x) {
-    double sum = 1.0, term = 1.0;
-    for (int k = 1; k < 64; ++k) {
-      term *= (x / (2.0 * k)) * (x / (2.0 * k));
-      sum += term;
-      if (term < 1e-18 * sum) break;
-    }
-    return sum;
-  };
-  const double i0b = bessel_i0(beta);
+// Interpolation weights of lane L for window sample j of a wave-step of class `cls`: the lane sits pos = (L - e) / D
+// coarse samples after the window's reference sample (index N / 2), D = 64 >> grid; with q = floor(pos), x = pos - q the
+// N taps are the coarse samples q - N/2 + 1 .. q + N/2 (window samples j = q + 1 .. q + N; zero elsewhere).  The taps
+// are the interpolator that is EXACT for the N / 2 tones +-omega_k at the Chebyshev nodes of the band [-pi / r, pi / r]
+// (r = the class's design oversampling): sum_j w_j exp(i omega_k j) = exp(i omega_k x) -- N real equations for N real
+// weights, solved in long double.  Worst-case error of a unit tone anywhere in the band, float32 weights included:
+// 9e-8 (N = 10, r = 4), 6e-7 (N = 6, r = 8), 3e-7 (N = 4, r = 32); the 12-tap Kaiser-windowed sinc it replaces: 6e-7.
+// Layout [tap][lane].
+void zoom_weights(int cls, int lane_off, float* w) {
+  const int taps = zoom_taps(cls), N = zoom_ntap(cls), half = N / 2;
+  const long double D = (long double)(kZoomD >> zoom_grid(cls));
+  const long double band = 3.14159265358979323846264338327950288L / (long double)zoom_design_oversampling(cls);
   for (int lane = 0; lane < kWave; ++lane) {
-    const double pos = (double)(lane - lane_off) / D;
-    for (int j = 0; j < taps; ++j) {
-      const double x = (double)j - half - pos;
-      double v = 0.0;
-      if (std::fabs(x) < half) {
-        const double r = x / half;
-        const double win = bessel_i0(beta * std::sqrt(1.0 - r * r)) / i0b;
-        const double sinc = std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
-        v = sinc * win;
+    const long double pos = (long double)(lane - lane_off) / D;
+    const int q = (int)std::floor((double)pos);
+    const long double x = pos - (long double)q;
+    // nodes o = -half + 1 .. half; equations: cos and sin rows at the half positive Chebyshev nodes
+    long double M[10][11];
+    for (int k = 0; k < half; ++k) {
+      const long double om = band * std::cos((long double)(2 * k + 1) * 3.14159265358979323846264338327950288L / (long double)(2 * N));
+      for (int c = 0; c < N; ++c) {
+        const long double node = (long double)(c - half + 1);
+        M[k][c] = std::cos(om * node);
+        M[half + k][c] = std::sin(om * node);
       }
-      w[j * kWave + lane] = (float)v;
+      M[k][N] = std::cos(om * x);
+      M[half + k][N] = std::sin(om * x);
+    }
+    for (int c = 0; c < N; ++c) {  // Gauss-Jordan with partial pivoting
+      int piv = c;
+      for (int r = c + 1; r < N; ++r)
+        if (std::fabs((double)M[r][c]) > std::fabs((double)M[piv][c])) piv = r;
+      if (piv != c)
+        for (int k = 0; k <= N; ++k) std::swap(M[c][k], M[piv][k]);
+      const long double d = M[c][c];
+      for (int k = 0; k <= N; ++k) M[c][k] /= d;
+      for (int r = 0; r < N; ++r) {
+        if (r == c) continue;
+        const long double f = M[r][c];
+        if (f != 0.0L)
+          for (int k = 0; k <= N; ++k) M[r][k] -= f * M[c][k];
+      }
+    }
+    for (int j = 0; j < taps; ++j) w[j * kWave + lane] = 0.0f;
+    for (int c = 0; c < N; ++c) {
+      const int j = half + q + (c - half + 1);
+      if (j >= 0 && j < taps) w[j * kWave + lane] = (float)M[c][N];
     }
   }
 }
