@@ -608,7 +608,7 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       QI_HIP(hipMalloc((void**)&t.d_zoom_plane_band, owner.size() * sizeof(int32_t)));
       QI_HIP(hipMemcpy(t.d_zoom_plane_band, owner.data(), owner.size() * sizeof(int32_t), hipMemcpyHostToDevice));
       for (int g = 0; g < native::kZoomClasses; ++g)
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 1; ++e) {
           // (class 0 also serves the bands of classes 5 and 6 in calls with few records)
           const bool needed = t.zoom_count[g] > 0 || (g == 0 && t.zoom_count[5] + t.zoom_count[6] > 0);
           if (p->d_zoom_w[g][e] || !needed) continue;
@@ -719,9 +719,13 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
     QI_TRY(fft_c2c<double>(p->fft, rows, L, nbk, HIPFFT_FORWARD, st));
     for (int jj = 0; jj < nbk; ++jj) {
       const native::BandDesc& d = bands[q + jj];
-      if (d.mode != 1)
+      if (d.mode != 1) {
+        // zoom bands of the linear (styx) table: panel sample t is full-length sample t + n/2 - 1; the odd sample is a
+        // phase ramp on the band's baseband bins, exp(-2 pi i (k - k_c) / L), folded into the compact bank here
+        const double ramp = (d.mode >= 2 && !circular) ? -1.0 / (double)L : 0.0;
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
-                                              d.k_len, circular, 1.0 / (double)L, L, st));
+                                              d.k_len, circular, 1.0 / (double)L, L, st, ramp, d.k_len / 2));
+      }
       else
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L,
                                               static_cast<cplx<T>*>(t.Hfull) + (int64_t)d.bank_row * L, 0, L, circular,
@@ -1658,7 +1662,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         z.lvl_chunk0[g] = chunk0;
         z.lvl_nchunk[g] = znchunk[g];
         z.lvl_stat_base[g] = p2_stats + blk_stats + zstat_base[g];
-        z.lvl_weights[g] = p->d_zoom_w[g][z.lane_off];
+        z.lvl_weights[g] = p->d_zoom_w[g][0];  // (a lane's position in its window does not depend on the kind)
         chunk0 += znchunk[g];
       }
       int first = 0;

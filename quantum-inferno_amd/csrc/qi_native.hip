@@ -847,14 +847,22 @@ __global__ void __launch_bounds__(256) k_band_support(const double2* __restrict_
 // copy a window of a float64 spectrum row into working precision, scaled (and conjugated for the circular bank)
 template <typename T>
 __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict__ dst, int64_t k_lo, int64_t count,
-                              int conj, double scale, int64_t row_len) {
+                              int conj, double scale, int64_t row_len, double ramp, int64_t ramp_center) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   int64_t k = k_lo + i;  // the window may start at a negative bin: bins are taken modulo the row length
   if (k < 0) k += row_len;
   if (k >= row_len) k -= row_len;
   const double2 v = F[k];
-  dst[i] = mk<T>((T)(v.x * scale), (T)((conj ? -v.y : v.y) * scale));
+  double re = v.x * scale, im = (conj ? -v.y : v.y) * scale;
+  if (ramp != 0.0) {  // times exp(2 pi i ramp (i - ramp_center)): a time shift of the band's envelope (zoom engine)
+    double s, c;
+    sincospi(2.0 * ramp * (double)(i - ramp_center), &s, &c);
+    const double r2 = re * c - im * s;
+    im = re * s + im * c;
+    re = r2;
+  }
+  dst[i] = mk<T>((T)re, (T)im);
 }
 
 }  // namespace
@@ -1105,13 +1113,15 @@ int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double
 
 template <typename T>
 int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
-                       int64_t row_len, hipStream_t st) {
-  k_copy_window<T><<<(unsigned)ceil_div(count, 256), 256, 0, st>>>(F, dst, k_lo, count, conj, scale, row_len);
+                       int64_t row_len, hipStream_t st, double ramp, int64_t ramp_center) {
+  k_copy_window<T><<<(unsigned)ceil_div(count, 256), 256, 0, st>>>(F, dst, k_lo, count, conj, scale, row_len, ramp, ramp_center);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
-template int launch_copy_window<float>(const double2*, float2*, int64_t, int64_t, int, double, int64_t, hipStream_t);
-template int launch_copy_window<double>(const double2*, double2*, int64_t, int64_t, int, double, int64_t, hipStream_t);
+template int launch_copy_window<float>(const double2*, float2*, int64_t, int64_t, int, double, int64_t, hipStream_t, double,
+                                       int64_t);
+template int launch_copy_window<double>(const double2*, double2*, int64_t, int64_t, int, double, int64_t, hipStream_t,
+                                        double, int64_t);
 
 }  // namespace native
 }  // namespace qi

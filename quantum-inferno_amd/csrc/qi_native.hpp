@@ -167,7 +167,9 @@ int launch_block_taps_edge(double2* g, int w, int64_t n, double taper_e, const d
 // D = 64 >> g fine samples per coarse sample, M_g = (Lf / 64) << g coarse samples, S = 1 << g coarse samples per
 // wave-step (a wave-step = 64 consecutive outputs = the 64 lanes).  The interpolator has N = 10, 6 or 4 taps in
 // coarse-sample units (by the band's oversampling, see the classes below); a wave-step spans S coarse intervals, so its
-// window has N + S samples and every lane carries the N + S weights of its own position in it.
+// window has N + S - 1 samples and every lane carries the N + S - 1 weights of its own position in it.  (The one-sample
+// offset of the zero-padded linear correlation, output t = full-length sample t + n/2 - 1, is a phase ramp folded
+// into the band's compact bank at plan time, so a lane's position in its window is lane / D >= 0 for every kind.)
 constexpr int kZoomD = 64;  // fine samples per coarse sample at level 0 (= the lanes of a wave)
 constexpr int kZoomLevels = 5;   // coarse-grid levels
 // A band's CLASS = (grid level, interpolator).  Classes 0..4: grid level 0..4, bands oversampled >= 4 times on their
@@ -179,7 +181,7 @@ constexpr int zoom_grid(int cls) { return cls < kZoomLevels ? cls : 0; }
 constexpr int zoom_ntap(int cls) { return cls < kZoomLevels ? 10 : (cls == 5 ? 6 : 4); }
 constexpr int zoom_design_oversampling(int cls) { return cls < kZoomLevels ? 4 : (cls == 5 ? 8 : 32); }
 constexpr int zoom_span(int cls) { return 1 << zoom_grid(cls); }                   // S
-constexpr int zoom_taps(int cls) { return zoom_ntap(cls) + zoom_span(cls); }       // window samples per wave-step
+constexpr int zoom_taps(int cls) { return zoom_ntap(cls) + zoom_span(cls) - 1; }   // window samples per wave-step
 constexpr int zoom_steps(int cls) { return zoom_grid(cls) <= 2 ? 16 : (64 >> zoom_grid(cls)); }  // wave-steps per wave and band
                                                                                    // (window of <= 128 coarse samples)
 constexpr int kZoomOversample = 4;
@@ -259,7 +261,7 @@ int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st);
 template <typename T>
 int launch_copy_window(const double2* F, cplx<T>* dst, int64_t k_lo, int64_t count, int conj, double scale,
-                       int64_t row_len, hipStream_t st);
+                       int64_t row_len, hipStream_t st, double ramp = 0.0, int64_t ramp_center = 0);
 
 }  // namespace native
 }  // namespace qi

@@ -63,7 +63,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
   if ((int64_t)blockIdx.x >= a.n / ((int64_t)kZoomD * STEPS * NW)) return;  // this level has fewer groups along time
   const int nchunk = a.lvl_nchunk[LEVEL];
   const float* __restrict__ weights = a.lvl_weights[LEVEL];
-  constexpr int GRID = zoom_grid(LEVEL), HALF = zoom_ntap(LEVEL) / 2;
+  constexpr int GRID = zoom_grid(LEVEL), HALF = zoom_ntap(LEVEL) / 2 - 1;
   constexpr int WIN = (STEPS - 1) * S + TAPS;  // coarse samples one wave needs per band
   static_assert(WIN <= 2 * kWave, "the window of one wave must fit two registers of its lanes");
   constexpr bool TWO = WIN > kWave;  // the window spills into a second vector register
@@ -342,9 +342,9 @@ int launch_zoom2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, in
   return QI_OK;
 }
 
-// Interpolation weights of lane L for window sample j of a wave-step of class `cls`: the lane sits pos = (L - e) / D
-// coarse samples after the window's reference sample (index N / 2), D = 64 >> grid; with q = floor(pos), x = pos - q the
-// N taps are the coarse samples q - N/2 + 1 .. q + N/2 (window samples j = q + 1 .. q + N; zero elsewhere).  The taps
+// Interpolation weights of lane L for window sample j of a wave-step of class `cls`: the lane sits pos = L / D coarse
+// samples after the window's reference sample (index N / 2 - 1), D = 64 >> grid; with q = floor(pos), x = pos - q the
+// N taps are the coarse samples q - N/2 + 1 .. q + N/2 (window samples j = q .. q + N - 1; zero elsewhere).  The taps
 // are the interpolator that is EXACT for the N / 2 tones +-omega_k at the Chebyshev nodes of the band [-pi / r, pi / r]
 // (r = the class's design oversampling): sum_j w_j exp(i omega_k j) = exp(i omega_k x) -- N real equations for N real
 // weights, solved in long double.  Worst-case error of a unit tone anywhere in the band, float32 weights included:
@@ -387,7 +387,7 @@ void zoom_weights(int cls, int lane_off, float* w) {
     }
     for (int j = 0; j < taps; ++j) w[j * kWave + lane] = 0.0f;
     for (int c = 0; c < N; ++c) {
-      const int j = half + q + (c - half + 1);
+      const int j = (half - 1) + q + (c - half + 1);
       if (j >= 0 && j < taps) w[j * kWave + lane] = (float)M[c][N];
     }
   }

@@ -7,9 +7,5 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
 run1 A=1
-EXTRA=(--channels 2); run1 A=1
-EXTRA=(--channels 2); run1 QI_NATIVE_ZOOM_SHORT_FROM=1
-EXTRA=(--channels 4); run1 A=1
-EXTRA=(--channels 4); run1 QI_NATIVE_ZOOM_SHORT_FROM=8
-EXTRA=(--channels 8); run1 A=1
 run A=1
+run QI_NATIVE_ZOOM_SHORT=0
