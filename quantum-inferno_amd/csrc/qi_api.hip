@@ -312,23 +312,25 @@ struct qi_plan {
     int demod = 0;
     void* bank = nullptr;  // [rows][kBlk] complex filter spectra
     int32_t rows = 0;
-    native::BlockBand* d_bands = nullptr;  // all reach groups, group by group
     // Work items (one per workgroup, most expensive first) in two cuts: [0] few bands per workgroup -- many workgroups,
     // for calls with one or two records --, [1] many bands per workgroup -- fewer forward transforms of the same block
     // and fewer per-time planes, for batches that fill the chip anyway.
     struct ItemList {
+      native::BlockBand* d_bands = nullptr;  // all reach groups, group by group (cut 1 keeps some bands on long blocks)
+      std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
       native::BlockItem* d_items = nullptr;
       int32_t nitems = 0, nplanes = 0;
+      int32_t nlong = 0;        // long-block items, at the front of the list
       int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
       std::vector<native::BlockItem> h_items;  // host copy of d_items (the joint launch list is made from it)
     } var[2];
     int64_t max_blocks = 0;  // partial slots a band row needs
-    std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
     void release() {
       if (bank) (void)hipFree(bank);
-      if (d_bands) (void)hipFree(d_bands);
-      for (auto& v : var)
+      for (auto& v : var) {
+        if (v.d_bands) (void)hipFree(v.d_bands);
         if (v.d_items) (void)hipFree(v.d_items);
+      }
       *this = BlockTable();
     }
   } blk[3];
@@ -337,7 +339,7 @@ struct qi_plan {
   const void* shared_sig = nullptr;
   int64_t shared_C = 0;
   bool shared_valid = false;
-  int32_t* d_band_slots[3] = {nullptr, nullptr, nullptr};  // per table kind: partial slots each band's engine writes
+  int32_t* d_band_slots[3][2] = {};  // per table kind and item cut: partial slots each band's engine writes
   int native_zoom = 1;         // use the zoom engine for narrow-spectrum bands (0: one-pass loader of pass 2)
   int native_zoom_short = 1;      // bands oversampled >= 8 / >= 32 times on the coarsest grid use 6- / 4-tap interpolators
   int native_zoom_short_from = 4; // ... in calls (tiles) of at least this many records; below, they run with the 10-tap class
@@ -369,10 +371,12 @@ struct qi_plan {
   FusedCarry carry;
   native::DualItem* d_dual[2] = {nullptr, nullptr};  // joint block launch of qi_cwt_stx (styx + Stockwell tables) per item cut, built on first use
   int32_t n_dual[2] = {0, 0};
+  int32_t n_dual_long[2] = {0, 0};  // long-block items at the front of d_dual
   bool dual_valid[2] = {false, false};
   int native_fuse = 4;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
                                // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
+  int native_blk_long = 1;     // narrow Gaussian bands of the 1024-sample reach group in 8192-sample blocks (75 % of the outputs kept instead of 50 %)
   int native_blk_half = 1;     // block bands whose filter spectrum lies in the lower half of the block spectrum: eight weights, pruned first pass
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
   int64_t native_tile = 0;     // qi_cwt_stx: at most this many records per joint tile (0: as many as the scratch holds)
@@ -764,72 +768,101 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
                                 1.0 / (double)native::kBlk, st));
   bt.rows = rows;
   bt.demod = demod;
-  const int wqs[3] = {1, 2, 4};
-  std::vector<native::BlockBand> list;
-  int32_t group_first[3] = {0, 0, 0}, group_count[3] = {0, 0, 0};
-  for (int g = 0; g < 3; ++g) {
-    const int32_t first = (int32_t)list.size();
-    for (int32_t r = 0; r < rows; ++r) {
-      if (picks[r].wq != wqs[g]) continue;
-      native::BlockBand b;
-      memset(&b, 0, sizeof(b));
-      b.out_band = picks[r].band;
-      b.bank_row = r;
-      b.shift = (int32_t)picks[r].shift;
-      b.analytic = p->native_blk_analytic ? picks[r].analytic : 0;
-      b.kappa_int = (int32_t)std::floor(picks[r].kappa);
-      b.kappa_frac = (float)(picks[r].kappa - std::floor(picks[r].kappa));
-      b.cw = (float)picks[r].cw;
-      b.amp = (float)picks[r].amp;
-      // weights >= 2^-30 of the peak: |cw dk| <= sqrt(30)
-      const double half = std::ceil(std::sqrt(30.0) / picks[r].cw);
-      if (b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
-        b.narrow = 1;
-        b.klo = (int32_t)((((int64_t)std::llround(picks[r].kappa) - 128) % native::kBlk + native::kBlk) % native::kBlk);
-        const int ba = b.klo >> 8;
-        b.rot_a[0] = (float)std::cos(2.0 * M_PI * ba / 16.0);
-        b.rot_a[1] = (float)std::sin(2.0 * M_PI * ba / 16.0);
-        b.rot_b[0] = (float)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
-        b.rot_b[1] = (float)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
-      } else if (b.analytic && p->native_blk_half && picks[r].kappa - half - 1.0 >= 0.0 &&
-                 picks[r].kappa + half + 1.0 < (double)(native::kBlk / 2)) {
-        b.narrow = 2;  // every weight above 2^-30 of the peak lies in the lower half of the block spectrum
-      }
-      for (int k = 0; k < 4; ++k) {
-        // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
-        const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
-        const double ang = -2.0 * M_PI * (double)m / (double)p->n;
-        b.rot[2 * k] = (float)std::cos(ang);
-        b.rot[2 * k + 1] = (float)std::sin(ang);
-      }
-      list.push_back(b);
-    }
-    group_first[g] = first;
-    group_count[g] = (int32_t)list.size() - first;
-    if (group_count[g] == 0) continue;
-    const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
-    if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
-    for (int32_t q = first; q < (int32_t)list.size(); ++q) bt.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
-  }
+  // reach groups: taps within 256, 512, 1024 samples (4096-sample blocks), and the long blocks (8192 samples) for the
+  // narrow Gaussian bands of the 1024-sample group whose spectrum lies in the lower half of the 8192-bin grid
+  constexpr int NG = 4;
+  const int wqs[NG] = {1, 2, 4, native::kBlkLongWq};
+  // first bin of the 256-bin window of a long band: centred on the band, kept inside the lower half of the 8192-bin grid
+  // (the half a long block holds)
+  auto long_window = [&](const BlockPick& pk) {
+    return std::min<int64_t>(std::max<int64_t>((int64_t)std::llround(2.0 * pk.kappa) - 128, 0), native::kBlk - 256);
+  };
+  auto long_ok = [&](const BlockPick& pk, int cut) {
+    if (cut == 0) return false;  // few records: the long blocks' own launch would cost more than the blocks save
+    if (!p->native_blk_long || !p->native_blk_analytic || !p->native_blk_narrow || pk.wq != 4 || !pk.analytic) return false;
+    if (p->n < 4 * native::kBlkLong) return false;
+    const double half8 = std::ceil(std::sqrt(30.0) / (0.5 * pk.cw));  // weights >= 2^-30 of the peak on the 8192-bin grid
+    const int64_t klo8 = long_window(pk);
+    return 2.0 * pk.kappa - half8 - 1.0 >= (double)klo8 && 2.0 * pk.kappa + half8 + 1.0 <= (double)(klo8 + 255);
+  };
   int64_t split_blocks = 0;
   if (kind == 0 && p->nsplit > 0) {
     split_blocks = ceil_div(p->n, native::block_valid((int)(p->native_split_e / 512)));
     if (split_blocks > bt.max_blocks) bt.max_blocks = split_blocks;
-    for (int32_t sb = 0; sb < p->nsplit; ++sb) bt.h_bands.push_back({p->h_split_bands[sb], (int32_t)split_blocks});
+    for (auto& il : bt.var)
+      for (int32_t sb = 0; sb < p->nsplit; ++sb) il.h_bands.push_back({p->h_split_bands[sb], (int32_t)split_blocks});
   }
   for (int v = 0; v < 2; ++v) {
     auto& il = bt.var[v];
+    std::vector<native::BlockBand> list;
+    int32_t group_first[NG] = {0, 0, 0, 0}, group_count[NG] = {0, 0, 0, 0};
+    for (int g = 0; g < NG; ++g) {
+      const int32_t first = (int32_t)list.size();
+      for (int32_t r = 0; r < rows; ++r) {
+        const bool is_long = long_ok(picks[r], v);
+        if (g == 3 ? !is_long : (picks[r].wq != wqs[g] || is_long)) continue;
+        native::BlockBand b;
+        memset(&b, 0, sizeof(b));
+        b.out_band = picks[r].band;
+        b.bank_row = r;
+        b.shift = (int32_t)picks[r].shift;
+        b.analytic = p->native_blk_analytic ? picks[r].analytic : 0;
+        const double grid = is_long ? 2.0 : 1.0;  // the band on the 8192-bin grid of a long block: twice the bins
+        const double kappa = grid * picks[r].kappa, cw = picks[r].cw / grid;
+        b.kappa_int = (int32_t)std::floor(kappa);
+        b.kappa_frac = (float)(kappa - std::floor(kappa));
+        b.cw = (float)cw;
+        b.amp = (float)(picks[r].amp / grid);
+        // weights >= 2^-30 of the peak: |cw dk| <= sqrt(30)
+        const double half = std::ceil(std::sqrt(30.0) / cw);
+        if (b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
+          b.narrow = 1;
+          b.klo = is_long ? (int32_t)long_window(picks[r])
+                          : (int32_t)((((int64_t)std::llround(kappa) - 128) % native::kBlk + native::kBlk) % native::kBlk);
+          const int ba = b.klo >> 8;
+          b.rot_a[0] = (float)std::cos(2.0 * M_PI * ba / 16.0);
+          b.rot_a[1] = (float)std::sin(2.0 * M_PI * ba / 16.0);
+          b.rot_b[0] = (float)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+          b.rot_b[1] = (float)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+          b.rot8_a[0] = (float)std::cos(M_PI * ba / 16.0);  // exp(2 pi i 256 b / 8192)
+          b.rot8_a[1] = (float)std::sin(M_PI * ba / 16.0);
+          b.rot8_b[0] = (float)std::cos(M_PI * (ba + 1) / 16.0);
+          b.rot8_b[1] = (float)std::sin(M_PI * (ba + 1) / 16.0);
+        } else if (b.analytic && p->native_blk_half && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)(native::kBlk / 2)) {
+          b.narrow = 2;  // every weight above 2^-30 of the peak lies in the lower half of the block spectrum
+        }
+        for (int k = 0; k < 4; ++k) {
+          // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
+          const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
+          const double ang = -2.0 * M_PI * (double)m / (double)p->n;
+          b.rot[2 * k] = (float)std::cos(ang);
+          b.rot[2 * k + 1] = (float)std::sin(ang);
+        }
+        {
+          const int64_t m1 = picks[r].shift % p->n;  // one sample: the odd sample of a long block's pair
+          b.rot1[0] = (float)std::cos(-2.0 * M_PI * (double)m1 / (double)p->n);
+          b.rot1[1] = (float)std::sin(-2.0 * M_PI * (double)m1 / (double)p->n);
+        }
+        list.push_back(b);
+      }
+      group_first[g] = first;
+      group_count[g] = (int32_t)list.size() - first;
+      if (group_count[g] == 0) continue;
+      const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
+      if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
+      for (int32_t q = first; q < (int32_t)list.size(); ++q) il.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
+    }
     const int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
     std::vector<native::BlockItem> items;
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < NG; ++g) {
       const int32_t first = group_first[g], count = group_count[g];
       if (count == 0) continue;
       // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
       const int32_t nchunk = (int32_t)ceil_div(count, per_wg);
       const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
       if (tune_env("QI_NATIVE_VERBOSE"))
-        fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
-                256 * wqs[g], count,
+        fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d%s: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
+                g == 3 ? 1024 : 256 * wqs[g], g == 3 ? " (8192-sample blocks)" : "", count,
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.analytic != 0; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 1; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 2; }),
@@ -850,10 +883,13 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
         il.nplanes += 1;
       }
     }
-    std::stable_sort(items.begin(), items.end(),
-                     [](const native::BlockItem& x, const native::BlockItem& y) { return x.band_count > y.band_count; });
+    std::stable_sort(items.begin(), items.end(), [](const native::BlockItem& x, const native::BlockItem& y) {
+      const bool lx = x.wq == native::kBlkLongWq, ly = y.wq == native::kBlkLongWq;
+      return lx != ly ? lx : x.band_count > y.band_count;
+    });
     for (size_t i = 0; i < items.size(); ++i) items[i].stat_slot = (int32_t)i;
     il.nitems = (int32_t)items.size();
+    il.nlong = (int32_t)std::count_if(items.begin(), items.end(), [](const native::BlockItem& x) { return x.wq == native::kBlkLongWq; });
     if (kind == 0 && p->nsplit > 0) {
       // the edge items of the split bands ride at the end of the launch (light items: they fill its tail); each split
       // band has a per-time plane and one partial slot per block like the other bands of the launch
@@ -866,11 +902,11 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       il.nedge_items = (int32_t)items.size() - il.nitems;
     }
     il.h_items = items;
+    QI_HIP(hipMalloc((void**)&il.d_bands, list.size() * sizeof(native::BlockBand)));
+    QI_HIP(hipMemcpy(il.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
     QI_HIP(hipMalloc((void**)&il.d_items, items.size() * sizeof(native::BlockItem)));
     QI_HIP(hipMemcpy(il.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
   }
-  QI_HIP(hipMalloc((void**)&bt.d_bands, list.size() * sizeof(native::BlockBand)));
-  QI_HIP(hipMemcpy(bt.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
   QI_HIP(hipStreamSynchronize(st));
   bt.ready = true;
   return QI_OK;
@@ -1195,8 +1231,10 @@ int build_dual_items(qi_plan* p, int cut) {
     }
   }
   std::stable_sort(dual.begin(), dual.end(), [](const native::DualItem& x, const native::DualItem& y) {
-    return x.count0 + x.count2 > y.count0 + y.count2;
+    const bool lx = x.wq == native::kBlkLongWq, ly = y.wq == native::kBlkLongWq;
+    return lx != ly ? lx : x.count0 + x.count2 > y.count0 + y.count2;
   });
+  p->n_dual_long[cut] = (int32_t)std::count_if(dual.begin(), dual.end(), [](const native::DualItem& x) { return x.wq == native::kBlkLongWq; });
   dual.insert(dual.end(), edge.begin(), edge.end());
   if (dual.empty()) return QI_OK;
   QI_HIP(hipMalloc((void**)&p->d_dual[cut], dual.size() * sizeof(native::DualItem)));
@@ -1381,14 +1419,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // cleared when the finalisation knows each band's slot count; only the short-atom table (a second pass-2 geometry
   // plus the edge slot at the end of the row) keeps the cleared layout.
   const bool clear_parts = shorts;
-  if (!shorts && !p->d_band_slots[kind]) {
+  if (!shorts && !p->d_band_slots[kind][cut]) {
     std::vector<int32_t> slots((size_t)B, 0);
     for (int32_t r : p->nat[kind].h_rows) slots[r] = (int32_t)nblk_max;
     for (const auto& z : p->nat[kind].h_zoom) slots[z.first] = (int32_t)native::zoom_groups(n, z.second);
     if (blocks)
-      for (const auto& b : bt.h_bands) slots[b.first] = b.second;
-    QI_HIP(hipMalloc((void**)&p->d_band_slots[kind], slots.size() * sizeof(int32_t)));
-    QI_HIP(hipMemcpy(p->d_band_slots[kind], slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+      for (const auto& b : bt.var[cut].h_bands) slots[b.first] = b.second;
+    QI_HIP(hipMalloc((void**)&p->d_band_slots[kind][cut], slots.size() * sizeof(int32_t)));
+    QI_HIP(hipMemcpy(p->d_band_slots[kind][cut], slots.data(), slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   // scratch regions, each [Ct][...] without per-channel padding
   // qi_cwt_stx: the Stockwell call can take its spectra from the even bins of the zero-padded spectra the CWT call
@@ -1486,6 +1524,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       native::BlockArgs<T> b{};
       b.n = n;
       b.nitems = il.nitems;
+      b.nlong = il.nlong;
       b.nedge_items = il.nedge_items;
       b.nsplit = nsplit;
       b.edge_band = p->d_split_bands;
@@ -1493,7 +1532,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.edge_part = zadd;
       b.panel_bands = (int32_t)B;
       b.items = il.d_items;
-      b.bands = bt.d_bands;
+      b.bands = il.d_bands;
       b.bank = static_cast<const cplx<T>*>(bt.bank);
       b.sig = sig + c0 * n;
       b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
@@ -1523,13 +1562,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
         QI_TRY(build_dual_items(p, cut));
         const int32_t n_edge = p->blk[0].var[cut].nedge_items;
         const native::DualItem* items = p->d_dual[cut];
-        int32_t count = p->n_dual[cut];
+        int32_t count = p->n_dual[cut], nlong = p->n_dual_long[cut];
         if (phase == 1) count -= n_edge;
         if (phase == 2) {
           items += count - n_edge;
           count = n_edge;
+          nlong = 0;
         }
-        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, ct, bs));
+        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, nlong, ct, bs));
       } else {
         if (finishing) QI_TRY(native::launch_block<T>(finish->blk, finish->demod, finish->ct, bs));
         QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
@@ -1753,7 +1793,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       tc.B = B;
       tc.nbk = nbk;
       tc.stat_slots = stat_slots;
-      tc.band_slots = p->d_band_slots[kind];
+      tc.band_slots = p->d_band_slots[kind][cut];
       if (deferring) {
         defer->tail = tc;
         defer->ws_used = (size_t)(w - p->ws);
@@ -1778,7 +1818,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
                                     want_stat ? part_stat : nullptr,
                                     want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                                     want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, B, nbk, stat_slots,
-                                    shorts ? nullptr : p->d_band_slots[kind], st));
+                                    shorts ? nullptr : p->d_band_slots[kind][cut], st));
     else if (time_via_part)
       QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
                                            shorts ? edge_time : nullptr, p->edge_wmax, st));
@@ -1786,7 +1826,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr,
                              want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
                              want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, ct, B, nbk, stat_slots,
-                             st, shorts ? nullptr : p->d_band_slots[kind]));
+                             st, shorts ? nullptr : p->d_band_slots[kind][cut]));
     p->prof.end(QI_STAGE_EPILOGUE, st);
   }
   return QI_OK;
@@ -2102,6 +2142,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLK_BANDS_BATCH")) p->native_blk_bands_batch = atoi(e) > 0 ? atoi(e) : p->native_blk_bands_batch;
   if (const char* e = tune_env("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_LONG")) p->native_blk_long = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -2171,8 +2212,9 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-  for (auto* b : p->d_band_slots)
-    if (b) (void)hipFree(b);
+  for (auto& per_cut : p->d_band_slots)
+    for (auto* b : per_cut)
+      if (b) (void)hipFree(b);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)
       if (w) (void)hipFree(w);
@@ -2212,9 +2254,9 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
   }
   p->nat[bank].release();
   if (bank == QI_BANK_STYX) p->blk[0].release();
-  if (p->d_band_slots[bank]) {
-    (void)hipFree(p->d_band_slots[bank]);
-    p->d_band_slots[bank] = nullptr;
+  for (auto*& b : p->d_band_slots[bank]) {
+      if (b) (void)hipFree(b);
+    b = nullptr;
   }
   double* d_par = nullptr;
   QI_HIP(hipMalloc((void**)&d_par, (size_t)4 * B * sizeof(double)));
@@ -2360,9 +2402,9 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
   p->nb_stx = 0;  // committed below, once every table of the native engine has been built
   p->nat[2].release();
   p->blk[2].release();
-  if (p->d_band_slots[2]) {
-    (void)hipFree(p->d_band_slots[2]);
-    p->d_band_slots[2] = nullptr;
+  for (auto*& b : p->d_band_slots[2]) {
+      if (b) (void)hipFree(b);
+    b = nullptr;
   }
   if (native_wanted(p, 2)) {
     // support of exp2(-(coef k)^2) above 2^-30: |k| <= sqrt(30) / coef (float64: above 2^-50)

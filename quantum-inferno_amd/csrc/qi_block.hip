@@ -29,6 +29,9 @@ constexpr int kBlkThreads = 256;
 #ifndef QI_BLK_WAVES
 #define QI_BLK_WAVES 3  // waves per SIMD the block kernel is compiled for (register budget 512 / QI_BLK_WAVES)
 #endif
+#ifndef QI_BLK_LONG_WAVES
+#define QI_BLK_LONG_WAVES 2  // the same for the long-block kernels (they hold the even samples of a band while its odd samples are transformed)
+#endif
 #ifdef QI_NATIVE_DEBUG
 #define QI_BDBG(bit) (a.debug & (bit))
 #else
@@ -48,10 +51,18 @@ constexpr int kBlkThreads = 256;
 #define QI_BSTAMP(k)
 #endif
 constexpr int kBlkPad = 257;  // k0-stride of the second exchange image (conflict-free transposed reads)
+constexpr int kBlkRow1 = 272;  // row stride of the first exchange image (see fft4096_tail)
+constexpr int kBlkBuf = 16 * kBlkRow1;  // elements of the exchange buffer (>= 16 * kBlkPad)
 
 template <typename T>
 __device__ __forceinline__ cplx<T> cconj(cplx<T> v) {
   return mk<T>(v.x, -v.y);
+}
+// e + W_64^(-K) o
+template <typename T, int K>
+__device__ __forceinline__ cplx<T> cadd_tw(cplx<T> e, cplx<T> o) {
+  const cplx<T> t = mul_tw64<T, K, -1>(o);
+  return mk<T>(e.x + t.x, e.y + t.y);
 }
 
 // exchange between the half-waves: afterwards lanes 0-31 hold (their own a, the a of lane + 32) and lanes 32-63
@@ -66,6 +77,18 @@ __device__ __forceinline__ void half_swap(float& a, float& b) {
 template <typename T, int... Cs>
 __device__ __forceinline__ void rotate_rows16(cplx<T> (&S)[16], cplx<T> r0, std::integer_sequence<int, Cs...>) {
   ((S[Cs] = mul_tw64<T, 2 * Cs, -1>(cmul(S[Cs], r0))), ...);
+}
+
+// X[c] = E[c] + conj-twiddle * W_64^(-2 c) * O[c]   (long blocks: the 8192-point spectrum from its two 4096-point halves)
+template <typename T, int... Cs>
+__device__ __forceinline__ void long_combine(cplx<T> (&X)[16], const cplx<T> (&E)[16], const cplx<T> (&O)[16], cplx<T> w8c,
+                                             std::integer_sequence<int, Cs...>) {
+  (((void)(X[Cs] = cadd_tw<T, 2 * Cs>(E[Cs], cmul(O[Cs], w8c)))), ...);
+}
+// S[c] *= r0 * exp(-i pi c / 32), c = 0..15 (W_64^(-c))
+template <typename T, int... Cs>
+__device__ __forceinline__ void long_rotate(cplx<T> (&S)[16], cplx<T> r0, std::integer_sequence<int, Cs...>) {
+  ((S[Cs] = mul_tw64<T, Cs, -1>(cmul(S[Cs], r0))), ...);
 }
 
 // v[brev(q)] *= w^q, q = 1..15, powers by products of w, w^2, w^4, w^8 (depth <= 4 roundings)
@@ -163,17 +186,22 @@ template <typename T, int DIR>
 __device__ __forceinline__ void fft4096_tail(cplx<T> (&v)[16], cplx<T>* __restrict__ buf,
                                              const cplx<T>* __restrict__ tw256, int tid, int col) {
   __syncthreads();  // the previous transform's readers are done with buf
+  // First exchange image: row q2 (stride kBlkRow1 = 272: a row and the next one sit 16 elements apart modulo 32), column
+  // c at position c ^ ((c >> 4) & 1).  With the column order of this kernel (lanes 0-31 even, 32-63 odd columns) the
+  // sixteen lanes of a ds_write_b64 group then hit sixteen different bank pairs, and so do the 2 x 16 lanes of a
+  // ds_read_b64 group below (k0 = 0..15 of rows q2t and q2t + 1): no bank conflicts on either side.
   {
     cplx<T> t[16];
 #pragma unroll
     for (int q2 = 0; q2 < 16; ++q2) t[q2] = v[brev(q2, 4)];
+    const int pos = col ^ ((col >> 4) & 1);
 #pragma unroll
-    for (int q2 = 0; q2 < 16; ++q2) buf[q2 * 256 + col] = t[q2];
+    for (int q2 = 0; q2 < 16; ++q2) buf[q2 * kBlkRow1 + pos] = t[q2];
   }
   __syncthreads();
   const int k0 = tid & 15, q2t = tid >> 4;
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) v[k1] = buf[q2t * 256 + 16 * k1 + k0];
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = buf[q2t * kBlkRow1 + 16 * k1 + (k0 ^ (k1 & 1))];
   fft_reg<T, 16, DIR>(v);  // over k1 -> q1
 #pragma unroll
   for (int q1 = 1; q1 < 16; ++q1) {
@@ -474,6 +502,236 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
                                         s_red, w);
 }
 
+// ---- long blocks: 8192 record samples, the narrow Gaussian bands of the 1024-sample reach group ----------------------
+// Half of a 4096-sample block of that group is overlap.  An 8192-sample block keeps 6144 of its outputs (75 %) and costs
+// no more per point: the spectrum of the 8192 samples (bins k < 4096 only: the bands are analytic) is
+// X[k] = E[k] + W_8192^-k O[k] from the 4096-point transforms of the even and the odd samples, and -- the upper half of
+// the filtered spectrum being empty -- the 8192-point inverse is two 4096-point inverses, of Y[k] for the even output
+// samples and of Y[k] W_8192^k for the odd ones.  A thread ends up with both samples of a pair (2 q', 2 q' + 1): one
+// 16-byte store per pair, a wave's stores are one kilobyte run.
+template <typename T, bool CIRC>
+__device__ __forceinline__ void block_forward8(const T* __restrict__ sig, int64_t n, int64_t t0, cplx<T> (&S)[16],
+                                               cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256, cplx<T> w,
+                                               cplx<T> w8, int tid, int col) {
+  cplx<T> O[16];
+#pragma unroll
+  for (int par = 1; par >= 0; --par) {  // odd samples first (kept in O), then the even ones (in S)
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      int64_t t = t0 + 2 * (col + 256 * b) + par;
+      T x;
+      if (CIRC) {
+        t = (t + n) & (n - 1);
+        x = sig[t];
+      } else {
+        x = (t >= 0 && t < n) ? sig[t] : T(0);
+      }
+      S[b] = mk<T>(x, T(0));
+    }
+    fft4096<T, -1>(S, buf, tw256, w, tid, col);
+    if (par == 1) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) O[c] = S[brev(c, 4)];
+    }
+  }
+  // X[col + 256 c] = E + W_8192^-(col + 256 c) O,  W_8192^-(256 c) = W_64^-(2 c)
+  const cplx<T> w8c = cconj<T>(w8);
+  cplx<T> t[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) t[c] = S[brev(c, 4)];
+  long_combine<T>(S, t, O, w8c, std::make_integer_sequence<int, 16>{});
+}
+
+// The bands [band_first, band_first + band_count) of the launch's list on long block `blk_i`, from its spectrum S
+// (natural order, bins col + 256 c of the 8192-bin grid).
+template <typename T, bool DEMOD, bool COEF, bool BITS>
+__device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i, int32_t band_first, int32_t band_count,
+                                           int32_t plane, int32_t stat_slot, cplx<T> (&S)[16], cplx<T>* __restrict__ buf,
+                                           const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
+                                           cplx<T> w, cplx<T> w8) {
+  constexpr int W = 1024, V = kBlkLongValid, NOUT = 12, C0 = 2, NW = kBlkThreads / kWave;  // pairs c = 2 .. 13 of a thread are kept
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  const int64_t blk = blk_i, ch = blockIdx.z, n = a.n;
+  const int64_t t0 = blk * V - W;  // record samples [t0, t0 + 8192), outputs [t0 + W, t0 + W + V)
+  if (!DEMOD) {
+    // half-sample offset of the Gabor atoms: exp(-i theta_k / 2) = exp(-i pi k / 8192), k = col + 256 c
+    float sn, cs;
+    sincospif(-(float)col * (1.0f / (float)kBlkLong), &sn, &cs);
+    long_rotate<T>(S, mk<T>((T)cs, (T)sn), std::make_integer_sequence<int, 16>{});
+  }
+  T col_p[2 * NOUT];
+#pragma unroll
+  for (int i = 0; i < 2 * NOUT; ++i) col_p[i] = T(0);
+  T mx = T(0);
+  double plogp = 0.0;
+  const uint32_t tb0 = (uint32_t)(t0 + 2 * (col + 256 * C0));  // first sample of this thread's first kept pair
+  int pending = -1, par = 0;
+  BlockBand bd_next = a.bands[band_first];
+  for (int jj = 0; jj < band_count; ++jj) {
+    const BlockBand bd = bd_next;
+    if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
+    // this thread's only bin with a weight above 2^-30 of the peak
+    const int kres = (col - bd.klo) & 255;
+    const int k = (bd.klo + kres) & (kBlk - 1);  // (the band lies in the lower half of the 8192-bin grid)
+    const bool first = (k >> 8) == (bd.klo >> 8);
+    const cplx<T> x = pick_pair16<T>(S, __builtin_amdgcn_readfirstlane(bd.klo >> 8), first);
+    const T dk = (T)(k - bd.kappa_int) - (T)bd.kappa_frac;
+    const T e = (T)bd.cw * dk;
+    const T r = (T)bd.amp * fast_exp2(-e * e);
+    const cplx<T> y = mk<T>(x.x * r, x.y * r);
+    cplx<T> wq = w, wq8 = w8;
+    asm volatile("" : "+v"(wq.x), "+v"(wq.y), "+v"(wq8.x), "+v"(wq8.y));
+    const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
+    const cplx<T> tw_odd = cmul(wq8, first ? mk<T>((T)bd.rot8_a[0], (T)bd.rot8_a[1]) : mk<T>((T)bd.rot8_b[0], (T)bd.rot8_b[1]));
+    cplx<T> v[16];
+    cplx<T> ph = mk<T>(T(1), T(0)), ph1 = ph;
+    if (DEMOD) {
+      const uint32_t m = (0u - (uint32_t)bd.shift * tb0) & (uint32_t)(n - 1);
+      float s, c;
+      sincospif((float)m * a.two_over_n, &s, &c);
+      ph = mk<T>((T)c, (T)s);
+      ph1 = mk<T>((T)bd.rot1[0], (T)bd.rot1[1]);
+    }
+    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
+    char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
+    char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    uint32_t tb = tb0;
+    asm volatile("" : "+v"(tb));
+    T rowacc = T(0), pl = T(0);
+    // demodulation phasor of pair i (its even sample): ph * R^i, R = r^2 (512 samples): groups of four pairs start from
+    // the exact-power seeds ph, ph R^4, ph R^8 (depth <= 4 roundings), inside a group the phasor advances by R
+    const cplx<T> R1 = mk<T>((T)bd.rot[2], (T)bd.rot[3]), R4 = mk<T>((T)bd.rot[6], (T)bd.rot[7]);
+    {
+      // both samples of a pair leave in one 16-byte store: the even samples wait in registers for the odd ones (taking
+      // one parity at a time with 8-byte stores fits 3 waves / SIMD only with spills and measured 40 % slower)
+      cplx<T> ze[NOUT];
+      sparse_head16<T>(v, y, om);  // even output samples
+      fft4096_tail<T, 1>(v, buf, tw256, tid, col);
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) ze[i] = v[brev(i + C0, 4)];
+      sparse_head16<T>(v, cmul(y, tw_odd), om);  // odd output samples: Y[k] W_8192^k
+      fft4096_tail<T, 1>(v, buf, tw256, tid, col);
+      if (pending >= 0 && tid == 0) {
+        double rs = 0.0;
+        for (int q = 0; q < NW; ++q) rs += s_red[par ^ 1][q];
+        a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + blk] = rs;
+      }
+      cplx<T> seed = ph, rcur = ph;
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        cplx<T> z[2] = {ze[i], v[brev(i + C0, 4)]};
+        if (DEMOD) {
+          if (i > 0) {
+            if ((i & 3) == 0) {
+              seed = cmul_rn(seed, R4);
+              rcur = seed;
+            } else {
+              rcur = cmul_rn(rcur, R1);
+            }
+          }
+          z[0] = cmul_rn(z[0], rcur);
+          z[1] = cmul_rn(z[1], cmul_rn(rcur, ph1));
+        }
+        const uint32_t tt = tb + 512u * (uint32_t)i;  // even sample of the pair
+        const bool inside = tt < (uint32_t)n;         // (n is even: the odd sample is inside with it)
+        T lg[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const T m2 = norm2(z[hh].x, z[hh].y);
+          if (BITS) lg[hh] = log2_t(sqrt_t(m2) + a.eps);
+          const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
+          col_p[2 * i + hh] += p;
+          rowacc += p;
+          mx = p > mx ? p : mx;
+          pl += plog2p(p);
+        }
+        if (COEF && inside)
+          stream_store(reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))),
+                       make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
+        if (BITS && inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
+      }
+    }
+    plogp += (double)pl;
+    if (a.part_band) {
+      const double rs = wave_sum((double)rowacc);
+      if (lane == 0) s_red[par][wv] = rs;
+      pending = bd.out_band;
+      par ^= 1;
+    }
+  }
+  T tot = T(0);
+  char* __restrict__ time_row = reinterpret_cast<char*>(
+      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + plane) * n : nullptr);
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    tot += col_p[2 * i] + col_p[2 * i + 1];
+    const uint32_t tt = tb0 + 512u * (uint32_t)i;
+    if (time_row && tt < (uint32_t)n)
+      *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(col_p[2 * i], col_p[2 * i + 1]);
+  }
+  const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
+  __syncthreads();  // the last band's wave sums are visible; buf is free
+  if (pending >= 0 && tid == 0) {
+    double rs = 0.0;
+    for (int q = 0; q < NW; ++q) rs += s_red[par ^ 1][q];
+    a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + blk] = rs;
+  }
+  if (a.part_stat) {
+    double* fin = reinterpret_cast<double*>(buf);
+    if (lane == 0) {
+      fin[wv] = r0;
+      fin[NW + wv] = r1;
+      fin[2 * NW + wv] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < NW; ++q) {
+        m = fin[q] > m ? fin[q] : m;
+        s1 += fin[NW + q];
+        s2 += fin[2 * NW + q];
+      }
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + stat_slot) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
+    }
+  }
+}
+
+template <typename T, bool DEMOD, bool COEF, bool BITS>
+__device__ __forceinline__ void long_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
+                                          const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave], cplx<T> w,
+                                          cplx<T> w8) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  cplx<T> S[16];
+  block_forward8<T, DEMOD>(a.sig + (int64_t)blockIdx.z * a.n, a.n, (int64_t)it.block * kBlkLongValid - 1024, S, buf, tw256, w, w8,
+                           tid, col);
+  long_bands<T, DEMOD, COEF, BITS>(a, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, S, buf, tw256, s_red, w, w8);
+}
+
+// joint launch: the Stockwell bands and the styx bands of the same long block (see dual_item)
+template <typename T, bool COEF, bool BITS>
+__device__ __forceinline__ void long_dual_item(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem& it,
+                                               cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
+                                               double (*s_red)[kBlkThreads / kWave], cplx<T> w, cplx<T> w8) {
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  const int64_t n = a0.n, t0 = (int64_t)it.block * kBlkLongValid - 1024;
+  const bool inside = t0 >= 0 && t0 + kBlkLong <= n;
+  const T* sig = a0.sig + (int64_t)blockIdx.z * n;
+  cplx<T> S[16];
+  if (it.count2 > 0 || inside) block_forward8<T, true>(sig, n, t0, S, buf, tw256, w, w8, tid, col);
+  if (it.count2 > 0)
+    long_bands<T, true, COEF, BITS>(a2, it.block, it.first2, it.count2, it.plane2, it.slot2, S, buf, tw256, s_red, w, w8);
+  if (it.count0 > 0) {
+    if (!inside) block_forward8<T, false>(sig, n, t0, S, buf, tw256, w, w8, tid, col);
+    long_bands<T, false, COEF, BITS>(a0, it.block, it.first0, it.count0, it.plane0, it.slot0, S, buf, tw256, s_red, w, w8);
+  }
+}
+
 // qi_cwt_stx: the Stockwell bands (a2) and the styx bands (a0) of the same block from ONE forward transform -- inside
 // the record its wrapped and its zero-extended loads are the same samples; the blocks that reach over a record end are
 // transformed a second time.
@@ -591,7 +849,7 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
 
 template <typename T, bool DEMOD, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T> a) {
-  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   __shared__ double s_red[2][kBlkThreads / kWave];
   const int tid = threadIdx.x;
@@ -627,10 +885,46 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   }
 }
 
+// long-block items (BlockItem::wq = kBlkLongWq) have kernels of their own: their register budget (the even samples of a
+// band are held while its odd samples are transformed) would spill inside k_block / k_block_dual
+template <typename T, bool DEMOD, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, QI_BLK_LONG_WAVES) k_block_long(BlockArgs<T> a, const BlockItem* __restrict__ items) {
+  __shared__ cplx<T> buf[kBlkBuf];
+  __shared__ cplx<T> tw256[256];
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  float s, c;
+  sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+  tw256[tid] = mk<T>((T)c, (T)s);
+  sincospif((float)col * (2.0f / 4096.0f), &s, &c);
+  const cplx<T> w = mk<T>((T)c, (T)s);
+  sincospif((float)col * (2.0f / 8192.0f), &s, &c);
+  const cplx<T> w8 = mk<T>((T)c, (T)s);
+  long_item<T, DEMOD, COEF, BITS>(a, items[blockIdx.x], buf, tw256, s_red, w, w8);
+}
+template <typename T, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, QI_BLK_LONG_WAVES) k_block_long_dual(BlockArgs<T> a0, BlockArgs<T> a2,
+                                                                                    const DualItem* __restrict__ items) {
+  __shared__ cplx<T> buf[kBlkBuf];
+  __shared__ cplx<T> tw256[256];
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  float s, c;
+  sincospif((float)tid * (2.0f / 256.0f), &s, &c);
+  tw256[tid] = mk<T>((T)c, (T)s);
+  sincospif((float)col * (2.0f / 4096.0f), &s, &c);
+  const cplx<T> w = mk<T>((T)c, (T)s);
+  sincospif((float)col * (2.0f / 8192.0f), &s, &c);
+  const cplx<T> w8 = mk<T>((T)c, (T)s);
+  long_dual_item<T, COEF, BITS>(a0, a2, items[blockIdx.x], buf, tw256, s_red, w, w8);
+}
+
 template <typename T, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockArgs<T> a0, BlockArgs<T> a2,
                                                                          const DualItem* __restrict__ items) {
-  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   __shared__ double s_red[2][kBlkThreads / kWave];
   const int tid = threadIdx.x;
@@ -669,7 +963,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
 // plane tau1 of the band holds the envelope samples tau = P tau2 + tau1 of its coarse grid at [tau2].
 template <typename T>
 __device__ __forceinline__ void zoom_coarse_plane(cplx<T>* __restrict__ plane0) {
-  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
@@ -723,14 +1017,14 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
 }
 template <typename T>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse2g(ZoomArgs<T> a0, ZoomArgs<T> a2) {
-  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   if (blockIdx.x < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false>(a0, blockIdx.x, buf, tw256);
   else zoom_coarse_plane_gather<T, true>(a2, blockIdx.x - (uint32_t)a0.planes, buf, tw256);
 }
 template <typename T, bool STX>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse_g(ZoomArgs<T> a) {
-  __shared__ cplx<T> buf[16 * kBlkPad];
+  __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   zoom_coarse_plane_gather<T, STX>(a, blockIdx.x, buf, tw256);
 }
@@ -863,24 +1157,71 @@ int launch_block_v(const BlockArgs<T>& a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-int block_valid(int wq) { return kBlk - 512 * wq; }
+int block_valid(int wq) { return wq == kBlkLongWq ? kBlkLongValid : kBlk - 512 * wq; }
+
+static int launch_block_long(const BlockArgs<float>& a, int demod, const BlockItem* items, int32_t nitems, int64_t n_channels,
+                             hipStream_t st) {
+  if (nitems <= 0) return QI_OK;
+  dim3 grid((unsigned)nitems, 1, (unsigned)n_channels);
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+#define QI_LONG(D, C, B) k_block_long<float, D, C, B><<<grid, kBlkThreads, 0, st>>>(a, items)
+  if (demod) {
+    if (coef && bits) QI_LONG(true, true, true);
+    else if (coef) QI_LONG(true, true, false);
+    else if (bits) QI_LONG(true, false, true);
+    else QI_LONG(true, false, false);
+  } else {
+    if (coef && bits) QI_LONG(false, true, true);
+    else if (coef) QI_LONG(false, true, false);
+    else if (bits) QI_LONG(false, false, true);
+    else QI_LONG(false, false, false);
+  }
+#undef QI_LONG
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+static int launch_block_long_dual(const BlockArgs<float>& a0, const BlockArgs<float>& a2, const DualItem* items, int32_t nitems,
+                                  int64_t n_channels, hipStream_t st) {
+  if (nitems <= 0) return QI_OK;
+  const bool coef = a0.coef != nullptr, bits = a0.bits != nullptr;
+  dim3 grid((unsigned)nitems, 1, (unsigned)n_channels);
+#define QI_LONG2(C, B) k_block_long_dual<float, C, B><<<grid, kBlkThreads, 0, st>>>(a0, a2, items)
+  if (coef && bits) QI_LONG2(true, true);
+  else if (coef) QI_LONG2(true, false);
+  else if (bits) QI_LONG2(false, true);
+  else QI_LONG2(false, false);
+#undef QI_LONG2
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
 
 template <>
 int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st) {
   if (a.nitems + a.nedge_items <= 0) return QI_OK;
-  dim3 grid((unsigned)(a.nitems + a.nedge_items), 1, (unsigned)n_channels);
-  return demod ? launch_block_v<float, true>(a, grid, st) : launch_block_v<float, false>(a, grid, st);
+  if (a.nlong > 0) QI_TRY(launch_block_long(a, demod, a.items, a.nlong, n_channels, st));
+  BlockArgs<float> rest = a;
+  rest.items += a.nlong;
+  rest.nitems -= a.nlong;
+  rest.nlong = 0;
+  if (rest.nitems + rest.nedge_items <= 0) return QI_OK;
+  dim3 grid((unsigned)(rest.nitems + rest.nedge_items), 1, (unsigned)n_channels);
+  return demod ? launch_block_v<float, true>(rest, grid, st) : launch_block_v<float, false>(rest, grid, st);
 }
 
 template <>
 int launch_block_dual<float>(const BlockArgs<float>& a0, const BlockArgs<float>& a2, const DualItem* items, int32_t nitems,
-                             int64_t n_channels, hipStream_t st) {
+                             int32_t nlong, int64_t n_channels, hipStream_t st) {
   if (nitems <= 0) return QI_OK;
   const bool coef = a0.coef != nullptr, bits = a0.bits != nullptr;
   if (coef != (a2.coef != nullptr) || bits != (a2.bits != nullptr) || a0.n != a2.n) {
     set_error("block engine: the joint launch needs the same panels from both transforms");
     return QI_ERR_STATE;
   }
+  if (nlong > 0) QI_TRY(launch_block_long_dual(a0, a2, items, nlong, n_channels, st));
+  items += nlong;
+  nitems -= nlong;
+  if (nitems <= 0) return QI_OK;
   dim3 grid((unsigned)nitems, 1, (unsigned)n_channels);
   if (coef && bits) k_block_dual<float, true, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
   else if (coef) k_block_dual<float, true, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);

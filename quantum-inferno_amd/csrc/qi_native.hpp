@@ -102,7 +102,16 @@ struct BlockBand {
   // pass of the inverse transform without its first radix-2 stage
   int32_t narrow, klo;
   float rot_a[2], rot_b[2];
+  // long blocks (BlockItem::wq = kBlkLongWq: 8192 record samples per block, 6144 outputs kept; narrow Gaussian bands of
+  // the 1024-sample reach group): the band on the 8192-bin grid -- kappa_int / kappa_frac / cw / amp / klo / rot_a /
+  // rot_b above are then in units of THAT grid --, exp(i pi b / 16) for b = klo / 256 and the next one (the twiddle of the
+  // odd output samples), and for the Stockwell demodulation exp(-2 pi i idx / n) (one sample)
+  float rot8_a[2], rot8_b[2];
+  float rot1[2];
 };
+constexpr int kBlkLongWq = 8;       // BlockItem::wq of a long block
+constexpr int kBlkLong = 2 * kBlk;  // record samples of a long block
+constexpr int kBlkLongValid = kBlkLong - 2048;  // outputs kept (taps within 1024 samples)
 struct BlockItem {  // one workgroup of the block launch
   int32_t wq;          // reach group: taps within 256 * wq samples; negative: the edge pieces (reach group -wq) of
                        // split band `band_first` for output block `block` (see EdgeSplitArgs)
@@ -121,6 +130,7 @@ struct BlockArgs {
   int64_t n;
   int32_t nitems, panel_bands;
   int32_t nedge_items, nsplit;  // edge items of the split bands, after the nitems band items
+  int32_t nlong;                // of the nitems band items, the first nlong are long-block items (a launch of their own)
   const int32_t* edge_band;     // [nsplit] device: panel row of each split band
   const cplx<T>* edge_bank;     // [nsplit][2][kBlk]
   const cplx<T>* edge_part;     // [C][nsplit][n]: the zoom engine's part of the split bands
@@ -145,7 +155,7 @@ template <typename T>
 int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st);
 // a0: styx table, a2: Stockwell table; both must agree on which panels (coefficients, bits) are stored
 template <typename T>
-int launch_block_dual(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem* items, int32_t nitems,
+int launch_block_dual(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem* items, int32_t nitems, int32_t nlong,
                       int64_t n_channels, hipStream_t st);
 int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,
                             hipStream_t st);

@@ -1,11 +1,20 @@
-run() { echo -n "[$*] "; env QI_TUNE=1 "$@" python bench.py --config 2 --channels 16 --cpu-seconds 0 --steps 10 --warmup 2 --settle-ms 250 2>/dev/null | python -c "
+run() { echo -n "[$*] "; env QI_TUNE=1 "$@" python bench.py --config 2 --channels 32 --cpu-seconds 0 --steps 8 --warmup 2 --settle-ms 250 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['step_roofline']['stage_ms_per_step'], d['stft']['ms_per_step'])"; }
-run1() { echo -n "[cfg1 $*] "; env QI_TUNE=1 "$@" python bench.py --cpu-seconds 0 --steps 300 --warmup 50 --settle-ms 250 --wrappers 0 "${EXTRA[@]}" 2>/dev/null | python -c "
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['step_roofline']['frac'], d['step_roofline']['stage_ms_per_step'], d['stft']['ms_per_step'])"; }
+run1() { echo -n "[cfg1 $*] "; env QI_TUNE=1 "$@" python bench.py --cpu-seconds 0 --steps 300 --warmup 50 --settle-ms 250 --wrappers 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
-run1 A=1
-run A=1
-run QI_NATIVE_ZOOM_SHORT=0
+run16() { echo -n "[cfg1x16 $*] "; env QI_TUNE=1 "$@" python bench.py --channels 16 --cpu-seconds 0 --steps 50 --warmup 10 --settle-ms 250 --wrappers 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
+run1 QI_NATIVE_BLK_LONG=0
+run1 QI_NATIVE_BLK_LONG=1
+run16 QI_NATIVE_BLK_LONG=0
+run16 QI_NATIVE_BLK_LONG=1
+run16 QI_NATIVE_BLK_LONG=0
+run16 QI_NATIVE_BLK_LONG=1
+run QI_NATIVE_BLK_LONG=0
+run QI_NATIVE_BLK_LONG=1
