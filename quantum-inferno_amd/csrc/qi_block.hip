@@ -382,52 +382,59 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
     char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
     char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
-    uint32_t tb = tb0;
-    asm volatile("" : "+v"(tb));  // keep the band-invariant addresses out of the loop-invariant hoisting
     T rowacc = T(0), pl = T(0);
-    cplx<T> rot[NOUT];  // demodulation phasor of output i: ph * r^i by binary powers r, r^2, r^4, r^8
-    if (DEMOD) {
-      rot[0] = ph;
-#pragma unroll
-      for (int i = 1; i < NOUT; ++i) {
-        const int low = i & -i;
-        const int k = low == 1 ? 0 : (low == 2 ? 1 : (low == 4 ? 2 : 3));
-        rot[i] = cmul_rn(rot[i - low], mk<T>((T)bd.rot[2 * k], (T)bd.rot[2 * k + 1]));
-      }
-    }
+    // demodulation phasor of output i: ph * r^i (r: 256 samples); every fourth one from the exact power r^4 (at most
+    // three roundings), the ones between advance by r -- held one at a time, not as an array of NOUT
+    const cplx<T> R1 = mk<T>((T)bd.rot[0], (T)bd.rot[1]), R4 = mk<T>((T)bd.rot[4], (T)bd.rot[5]);
     uint32_t tp = tb_pair;
-    asm volatile("" : "+v"(tp));
+    asm volatile("" : "+v"(tp));  // keep the band-invariant addresses out of the loop-invariant hoisting
+    // Two outputs at a time: demodulate, bring the two ADJACENT samples of a pair into one lane (half_swap), then
+    // everything else -- powers, sums, the 16-byte store -- on the pair.  `guard`: the block reaches past the end of the
+    // record (its last block only): pairs outside are neither stored nor summed.
+    auto finish_band = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
+      cplx<T> seed = ph, rcur = ph;
 #pragma unroll
-    for (int i = 0; i < NOUT; i += 2) {
-      cplx<T> z[2];
-      T lg[2];
+      for (int i = 0; i < NOUT; i += 2) {
+        cplx<T> z[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        z[h] = v[brev(i + h + WQ, 4)];
-        if (DEMOD) z[h] = cmul_rn(z[h], rot[i + h]);
-        const bool inside = tb + 256u * (uint32_t)(i + h) < (uint32_t)n;
-        const T m2 = norm2(z[h].x, z[h].y);
-        if (BITS) lg[h] = log2_t(sqrt_t(m2) + a.eps);
-        const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
-        col_p[i + h] += p;
-        rowacc += p;
-        mx = p > mx ? p : mx;
-        pl += plog2p(p);
-      }
-      const uint32_t tt = tp + 256u * (uint32_t)i;  // first sample of this lane's 16-byte pair
-      const bool inside = tt < (uint32_t)n;
-      if (COEF) {
+        for (int h = 0; h < 2; ++h) {
+          z[h] = v[brev(i + h + WQ, 4)];
+          if (DEMOD) {
+            if (i + h > 0) {
+              if (((i + h) & 3) == 0) {
+                seed = cmul_rn(seed, R4);
+                rcur = seed;
+              } else {
+                rcur = cmul_rn(rcur, R1);
+              }
+            }
+            z[h] = cmul_rn(z[h], rcur);
+          }
+        }
         half_swap(z[0].x, z[1].x);
         half_swap(z[0].y, z[1].y);
-        if (inside && !QI_BDBG(1))
+        const uint32_t tt = tp + 256u * (uint32_t)i;  // first sample of this lane's pair
+        const bool inside = !GUARD || tt < (uint32_t)n;
+        T lg[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const T m2 = norm2(z[h].x, z[h].y);
+          if (BITS) lg[h] = log2_t(sqrt_t(m2) + a.eps);
+          const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
+          col_p[i + h] += p;
+          rowacc += p;
+          mx = p > mx ? p : mx;
+          pl += plog2p(p);
+        }
+        if (COEF && inside && !QI_BDBG(1))
           stream_store(reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))),
                        make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
+        if (BITS && inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
       }
-      if (BITS) {
-        half_swap(lg[0], lg[1]);
-        if (inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
-      }
-    }
+    };
+    if (t0 + W + V > n) finish_band(std::true_type{});
+    else finish_band(std::false_type{});
     plogp += (double)pl;
     if (a.part_band) {
       const double r = wave_sum((double)rowacc);
@@ -449,12 +456,11 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
   char* __restrict__ time_row = reinterpret_cast<char*>(
       a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + plane) * n : nullptr);
 #pragma unroll
-  for (int i = 0; i < NOUT; i += 2) {
+  for (int i = 0; i < NOUT; i += 2) {  // (col_p holds the sums of this lane's PAIRS: see finish_band)
     tot += col_p[i] + col_p[i + 1];
-    T c0 = col_p[i], c1 = col_p[i + 1];
-    half_swap(c0, c1);
     const uint32_t tt = tb_pair + 256u * (uint32_t)i;
-    if (time_row && tt < (uint32_t)n) *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(c0, c1);
+    if (time_row && tt < (uint32_t)n)
+      *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(col_p[i], col_p[i + 1]);
   }
   const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
   __syncthreads();  // the last band's wave sums are visible; buf is free
@@ -617,6 +623,8 @@ __device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i,
         for (int q = 0; q < NW; ++q) rs += s_red[par ^ 1][q];
         a.part_band[((int64_t)ch * a.panel_bands + pending) * a.nblk + blk] = rs;
       }
+      auto finish_band = [&](auto guard) {  // guard: the block reaches past the end of the record (see block_bands)
+      constexpr bool GUARD = decltype(guard)::value;
       cplx<T> seed = ph, rcur = ph;
 #pragma unroll
       for (int i = 0; i < NOUT; ++i) {
@@ -634,7 +642,7 @@ __device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i,
           z[1] = cmul_rn(z[1], cmul_rn(rcur, ph1));
         }
         const uint32_t tt = tb + 512u * (uint32_t)i;  // even sample of the pair
-        const bool inside = tt < (uint32_t)n;         // (n is even: the odd sample is inside with it)
+        const bool inside = !GUARD || tt < (uint32_t)n;  // (n is even: the odd sample is inside with it)
         T lg[2];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -651,6 +659,9 @@ __device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i,
                        make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
         if (BITS && inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
       }
+      };
+      if (t0 + W + V > n) finish_band(std::true_type{});
+      else finish_band(std::false_type{});
     }
     plogp += (double)pl;
     if (a.part_band) {

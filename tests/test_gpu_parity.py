@@ -496,11 +496,13 @@ def test_native_engine_batches_match_single_records():
 
 
 @pytest.mark.parametrize("order", [3, 12])
-def test_float64_native_engine_vs_oracle(order):
+def test_float64_native_engine_vs_oracle(golden, order):
     """float64 records of 2^20 samples run on the native two-pass kernels in double arithmetic (the exact algorithm: no
     truncated atoms, no interpolation).  Against the oracle (pinned to the reference at this length by
     tests/test_oracle_golden.py::test_benchmark_length_rows) on a sample of bands of every kind, at the float64
-    tolerance; every band and every fused reduction against the hipFFT engine (the reference's algorithm on the GPU)."""
+    tolerance; every band and every fused reduction against the hipFFT engine (the reference's algorithm on the GPU);
+    and every band against the reference's own rows at this length (captured from a float32 record, so the reference
+    output carries ~1e-7 of SciPy's single-precision FFT: compared at 5e-7)."""
     from quantum_inferno_amd import _lib
 
     n, fs = 1 << 20, 1000.0
@@ -537,6 +539,14 @@ def test_float64_native_engine_vs_oracle(order):
         lean = getattr(nat, name)(xt[:, :], coef=False, reductions=True)
         assert torch.equal(lean.reduced, a.reduced)
         del a, b, lean
+    g = golden("large_n1048576.npz" if order == 3 else "large_n1048576_o12.npz")
+    x32 = torch.from_numpy(orc.synth_chirp(n, fs, dtype=np.float32).astype(np.float64)).cuda().unsqueeze(0)
+    rows = g[f"rows_o{order}"]
+    assert len(rows) == nb
+    for name in ("cwt", "stx"):
+        res = getattr(nat, name)(x32, coef=True, reductions=True)
+        check_digest(res, g, name, order, TOL_F32_RECORD[np.float64], rows)
+        del res
     # a batch of three records (tiles of the scratch) equals the single-record runs
     xb = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 3, np.float64) for c in range(3)])).cuda()
     if order == 3:

@@ -10,11 +10,12 @@ run16() { echo -n "[cfg1x16 $*] "; env QI_TUNE=1 "$@" python bench.py --channels
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
-run1 QI_NATIVE_BLK_LONG=0
-run1 QI_NATIVE_BLK_LONG=1
-run16 QI_NATIVE_BLK_LONG=0
-run16 QI_NATIVE_BLK_LONG=1
-run16 QI_NATIVE_BLK_LONG=0
-run16 QI_NATIVE_BLK_LONG=1
-run QI_NATIVE_BLK_LONG=0
-run QI_NATIVE_BLK_LONG=1
+B=QI_TFR_LIB=$PWD/quantum-inferno_amd/libqi_tfr_base.so
+run $B
+run A=1
+run $B
+run A=1
+run1 $B
+run1 A=1
+run1 $B
+run1 A=1
