@@ -424,7 +424,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
           const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
           col_p[i + h] += p;
           rowacc += p;
-          mx = p > mx ? p : mx;
+          mx = max_t(mx, p);
           pl += plog2p(p);
         }
         if (COEF && inside && !QI_BDBG(1))
@@ -651,7 +651,7 @@ __device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i,
           const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
           col_p[2 * i + hh] += p;
           rowacc += p;
-          mx = p > mx ? p : mx;
+          mx = max_t(mx, p);
           pl += plog2p(p);
         }
         if (COEF && inside)
@@ -829,7 +829,7 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
     const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
     if (time_row && inside) time_row[t] = p;
     rowacc += p;
-    mx = p > mx ? p : mx;
+    mx = max_t(mx, p);
     pl += plog2p(p);
   }
   const double r0 = wave_max((double)mx), r1 = wave_sum((double)rowacc), r2 = wave_sum((double)pl);

@@ -121,6 +121,9 @@ __device__ __forceinline__ void sincospi_as(double x, T* s, T* c) {
   }
 }
 
+// running maximum of non-negative powers in one v_max (a compare-and-select takes two instructions)
+__device__ __forceinline__ float max_t(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double max_t(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ float plog2p(float p) { return p * __log2f(fmaxf(p, 1e-37f)); }
 __device__ __forceinline__ double plog2p(double p) { return p > 0.0 ? p * log2(p) : 0.0; }
 

@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       col[i] += p;
       if (!QI_DBG(8)) {
         rowacc += p;
-        mx = p > mx ? p : mx;
+        mx = max_t(mx, p);
         pl += plog2p(p);
       }
     }
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256) k_edge_reduce(EdgeArgs<T> a, T* __restric
   for (int64_t i = tid; i < 2 * w; i += 256) {
     const double p = (double)ep[(e * 2 + (i >= w ? 1 : 0)) * a.wmax + (i >= w ? i - w : i)];
     sum += p;
-    mx = p > mx ? p : mx;
+    mx = max_t(mx, p);
     pl += (double)plog2p((T)p);
   }
   mx = wave_max(mx);

@@ -171,7 +171,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
       const T p = mul_rn(pscale, m2);
       colp[s] += p;
       rowacc += p;
-      mx = p > mx ? p : mx;
+      mx = max_t(mx, p);
       pl += plog2p(p);
     }
     plogp += (double)pl;
