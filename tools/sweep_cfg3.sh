@@ -10,12 +10,11 @@ run16() { echo -n "[cfg1x16 $*] "; env QI_TUNE=1 "$@" python bench.py --channels
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
-B=QI_TFR_LIB=$PWD/quantum-inferno_amd/libqi_tfr_base.so
-run $B
-run A=1
-run $B
-run A=1
-run1 $B
 run1 A=1
-run1 $B
+run1 QI_NATIVE_PAIR=1 QI_NATIVE_PAIR_PRIO=0
+run1 QI_NATIVE_PAIR=1 QI_NATIVE_PAIR_PRIO=1
 run1 A=1
+run1 QI_NATIVE_PAIR=1 QI_NATIVE_PAIR_PRIO=1
+run A=1
+run QI_NATIVE_PAIR=1 QI_NATIVE_PAIR_PRIO=0
+run QI_NATIVE_PAIR=1 QI_NATIVE_PAIR_PRIO=1
