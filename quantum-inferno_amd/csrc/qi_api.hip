@@ -295,7 +295,11 @@ struct qi_plan {
     int32_t nzoom = 0, zoom_count[native::kZoomClasses] = {0, 0, 0, 0, 0, 0, 0};
     int64_t zoom_planes = 0;  // 4096-sample planes of coarse storage per record
     int zoom_max_level = 0;
+    // float64 zoom (qi_zoom64.hip): the narrow-spectrum bands of a float64 table, by coarse-grid level
+    native::BandDesc* d_z64 = nullptr;
+    int32_t nz64 = 0, z64_first[native::kZ64Levels] = {}, z64_count[native::kZ64Levels] = {};
     void release() {
+      if (d_z64) (void)hipFree(d_z64);
       if (d_zoom) (void)hipFree(d_zoom);
       if (d_zoom_plane_band) (void)hipFree(d_zoom_plane_band);
       if (d_bands) (void)hipFree(d_bands);
@@ -354,6 +358,9 @@ struct qi_plan {
   int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
                            // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
                            // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
+  int native_z64 = 1;      // float64: narrow-spectrum bands at the decimated rate (coarse inverse FFT + 16-tap interpolation)
+  int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
+  double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level
   int native_f64 = 1;      // float64 plans run the two-pass kernels (exact algorithm, double arithmetic) at 2^20 / 2^21-point transforms
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen
@@ -547,6 +554,14 @@ bool native_wanted(const qi_plan* p, int kind) {
   return kind != 1 && is_pow2(p->n) && p->n >= (1 << 18) && Lf <= (1ll << 26);
 }
 
+// Widest spectrum support (bins) of a band that keeps a compact bank row: the one-pass loader's limit, or -- float64 with
+// the float64 zoom engine, which then takes every such band -- the widest band its finest grid (Lf / 4 samples) still
+// oversamples four times.
+bool z64_table(const qi_plan* p, int table) { return p->d.dtype == QI_F64 && p->native_z64 && table != 3; }
+int64_t narrow_limit(const qi_plan* p, int table, int64_t Lf) {
+  return z64_table(p, table) ? std::max<int64_t>(p->native_kmax, Lf >> (9 - p->native_z64_levels)) : p->native_kmax;
+}
+
 // Order the bands into launch groups: the wide bands are dealt out `native_group` per group (all in one group when
 // 0) so that a group's intermediate is small enough to stay in the last-level cache between pass 1 and pass 2; the
 // narrow bands are spread evenly over the groups.  `bands[j].out_band` must be set by the caller.
@@ -622,6 +637,42 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
           QI_HIP(hipMemcpy(p->d_zoom_w[g][e], w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
+    bands.swap(rest);
+  }
+  if (z64_table(p, kind)) {
+    // float64: every band with a compact row goes to the float64 zoom engine, on the coarsest grid that oversamples it
+    // four times
+    std::vector<native::BandDesc> rest;
+    std::vector<std::vector<native::BandDesc>> lvl(native::kZ64Levels);
+    for (const auto& d : bands) {
+      int g = -1;
+      if (d.mode == 0)
+        for (int q = 0; q < p->native_z64_levels && g < 0; ++q)
+          if (4 * (int64_t)d.k_len <= ((Lf / 64) << q)) g = q;
+      if (g >= 0) lvl[g].push_back(d);
+      else rest.push_back(d);
+    }
+    std::vector<native::BandDesc> z;
+    for (int g = 0; g < native::kZ64Levels; ++g) {
+      t.z64_first[g] = (int32_t)z.size();
+      t.z64_count[g] = (int32_t)lvl[g].size();
+      z.insert(z.end(), lvl[g].begin(), lvl[g].end());
+      if (!lvl[g].empty() && !p->d_z64_w[g]) {
+        const int log2d = 6 - g;
+        std::vector<double> w((size_t)(1 << log2d) * native::kZ64Taps);
+        native::z64_weights(log2d, w.data());
+        QI_HIP(hipMalloc((void**)&p->d_z64_w[g], w.size() * sizeof(double)));
+        QI_HIP(hipMemcpy(p->d_z64_w[g], w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
+    t.nz64 = (int32_t)z.size();
+    if (!z.empty()) {
+      QI_HIP(hipMalloc((void**)&t.d_z64, z.size() * sizeof(native::BandDesc)));
+      QI_HIP(hipMemcpy(t.d_z64, z.data(), z.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
+    }
+    if (tune_env("QI_NATIVE_VERBOSE"))
+      fprintf(stderr, "[qi plan] table %d: float64 zoom bands per level %d %d %d %d %d, two-pass bands %zu\n", kind, t.z64_count[0],
+              t.z64_count[1], t.z64_count[2], t.z64_count[3], t.z64_count[4], rest.size());
     bands.swap(rest);
   }
   t.h_rows.clear();
@@ -1012,7 +1063,7 @@ int make_native_table(qi_plan* p, int table, int circular, int64_t L, int32_t B,
     d.edge_slot = (int32_t)q;  // the edge list is in the order of `ids`
     d.add_row = add_row.empty() ? 0 : add_row[q];
     const int zc = zoom_class(p, table, L, len);
-    if (zc >= 0 || (len > 0 && len <= p->native_kmax)) {
+    if (zc >= 0 || (len > 0 && len <= narrow_limit(p, table, L))) {
       d.mode = zc >= 0 ? 2 + zc : 0;  // 0: one-pass loader of pass 2; 2 + c: zoom engine, class c
       d.k_lo = (int32_t)lo;
       d.k_len = (int32_t)len;
@@ -1838,7 +1889,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
 int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
   using T = double;
   const auto& t = p->nat[kind];
-  const int64_t n = p->n, B = t.nbands, Lf = t.Lf;
+  const int64_t n = p->n, B = kind == 2 ? p->nb_stx : p->nb[kind], Lf = t.Lf;
   constexpr int G = 8;
   const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
   const T* sig = static_cast<const T*>(sig_v);
@@ -1849,6 +1900,17 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     nc = nc < 1 ? 1 : (nc > grp.count ? grp.count : nc);
     nchunk.push_back(nc);
     chunk_total += nc;
+  }
+  // float64 zoom bands: one launch per coarse-grid level, its bands dealt to `zchunk` workgroups per tile
+  int zchunk[native::kZ64Levels] = {};
+  size_t e_z = 0;  // coarse storage of the largest level (the levels run one after the other)
+  for (int g = 0; g < native::kZ64Levels; ++g) {
+    if (t.z64_count[g] == 0) continue;
+    int nc = (int)ceil_div(p->native_wgs, nblk * C);
+    zchunk[g] = nc < 1 ? 1 : (nc > t.z64_count[g] ? t.z64_count[g] : nc);
+    chunk_total += zchunk[g];
+    const size_t bytes = (size_t)t.z64_count[g] * (size_t)((Lf / 64) << g) * sizeof(cplx<T>);
+    if (bytes > e_z) e_z = bytes;
   }
   if (chunk_total == 0) {
     set_error("float64 native table has no band");
@@ -1861,12 +1923,12 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   const size_t e_imd = (size_t)t.imd_slots * Lf * sizeof(cplx<T>);
   const size_t e_pb = (size_t)B * nblk * 8, e_ps = (size_t)stat_slots * 24;
   const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
-  const size_t per_chan = e_x + e_imd + e_pb + e_ps + e_tp;
-  if (p->ws_bytes < per_chan + 4096) {
-    set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 4096);
+  const size_t per_chan = e_x + e_imd + e_z + e_pb + e_ps + e_tp;
+  if (p->ws_bytes < per_chan + 8192) {
+    set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 8192);
     return QI_ERR_NOMEM;
   }
-  int64_t Ct = (int64_t)((p->ws_bytes - 4096) / per_chan);
+  int64_t Ct = (int64_t)((p->ws_bytes - 8192) / per_chan);
   if (Ct > C) Ct = C;
   p->shared_valid = false;
   char* w = p->ws;
@@ -1877,6 +1939,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   };
   cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
   cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
+  cplx<T>* Z = reinterpret_cast<cplx<T>*>(carve(e_z));
   double* part_band = reinterpret_cast<double*>(carve(e_pb));
   double* part_stat = reinterpret_cast<double*>(carve(e_ps));
   T* time_part = reinterpret_cast<T*>(carve(e_tp));
@@ -1928,6 +1991,43 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk[g], ct, st));
       p->prof.end(QI_STAGE_PASS2, st);
       chunk_base += nchunk[g];
+    }
+    for (int g = 0; g < native::kZ64Levels; ++g) {
+      if (t.z64_count[g] == 0) continue;
+      native::Z64Args z{};
+      z.Lf = Lf;
+      z.n = n;
+      z.log2d = 6 - g;
+      z.M = Lf >> z.log2d;
+      z.kind = kind;
+      z.nbands = t.z64_count[g];
+      z.panel_bands = (int32_t)B;
+      z.bands = t.d_z64 + t.z64_first[g];
+      z.X = X;
+      z.Hc = static_cast<const cplx<T>*>(t.Hc);
+      z.Z = Z;
+      z.weights = p->d_z64_w[g];
+      z.inv_len = a.inv_len;
+      z.two_over_len = a.two_over_len;
+      z.coef = a.coef;
+      z.bits = a.bits;
+      z.time_part = a.time_part;
+      z.part_band = a.part_band;
+      z.part_stat = a.part_stat;
+      z.nblk = nblk;
+      z.stat_stride = stat_slots;
+      z.chunk_base = chunk_base;
+      z.chunk_total = chunk_total;
+      z.power_scale = a.power_scale;
+      z.eps = a.eps;
+      p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
+      QI_TRY(native::launch_z64_gather(z, ct, st));
+      QI_TRY(fft_c2c<T>(p->fft, Z, z.M, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
+      p->prof.end(QI_STAGE_ZOOM_COARSE, st);
+      p->prof.begin(st, QI_STAGE_ZOOM);
+      QI_TRY(native::launch_z64_interp(z, zchunk[g], ct, st));
+      p->prof.end(QI_STAGE_ZOOM, st);
+      chunk_base += zchunk[g];
     }
     p->prof.begin(st, QI_STAGE_EPILOGUE);
     double* pb_out = want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr;
@@ -2148,6 +2248,11 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     if (v == 8 || v == 16) p->native_rows = (int)v;
   }
   if (const char* e = tune_env("QI_NATIVE_F64")) p->native_f64 = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_Z64")) p->native_z64 = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_Z64_LEVELS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= native::kZ64Levels) p->native_z64_levels = v;
+  }
   if (desc->dtype == QI_F64) {  // exact paths only: every band on the two-pass kernels, evaluated at the full length
     p->native_zoom = p->native_block = p->native_short = p->native_split = 0;
     p->native_rows = 8;
@@ -2215,6 +2320,8 @@ int qi_plan_destroy(qi_plan* p) {
   for (auto& per_cut : p->d_band_slots)
     for (auto* b : per_cut)
       if (b) (void)hipFree(b);
+  for (auto* w : p->d_z64_w)
+    if (w) (void)hipFree(w);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)
       if (w) (void)hipFree(w);
@@ -2439,7 +2546,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       d.out_band = j;
       const double kh = std::floor(cut / coef[j]);
       const int zc = 2 * kh + 1 < (double)p->n ? zoom_class(p, 2, p->n, (int64_t)(2 * kh + 1)) : -1;
-      if (zc >= 0 || (2 * kh + 1 <= (double)p->native_kmax && 2 * kh + 1 < (double)p->n)) {
+      if (zc >= 0 || (2 * kh + 1 <= (double)narrow_limit(p, 2, p->n) && 2 * kh + 1 < (double)p->n)) {
         d.mode = zc >= 0 ? 2 + zc : 0;
         d.k_lo = -(int32_t)kh;
         d.k_len = 2 * (int32_t)kh + 1;
@@ -2485,7 +2592,7 @@ int64_t qi_plan_stage_bands(const qi_plan* p, int which, int stage) {
   if (!p->nat[which].ready) return stage == QI_STAGE_INVERSE ? total : 0;
   int64_t blk = 0;
   if (which != 1 && p->blk[which].ready) blk = p->blk[which].rows;
-  const int64_t zoom = p->nat[which].nzoom;
+  const int64_t zoom = p->nat[which].nzoom + p->nat[which].nz64;
   if (stage == QI_STAGE_BLOCK) return blk;
   if (stage == QI_STAGE_ZOOM) return zoom;
   return stage == QI_STAGE_PASS2 ? total - blk - zoom : 0;

@@ -422,7 +422,12 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
   cplx<T>* tw = buf + C::BUF;
   __shared__ double s_red[2][C::TH / kWave];
   __shared__ double s_fin[3][C::TH / kWave];
+  __shared__ double ltab[sizeof(T) == 8 ? 128 : 1][2];  // float64: the log2 table of the entropy sums in LDS (log2_pos)
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  if (sizeof(T) == 8 && tid < 128) {
+    ltab[tid][0] = kLog2Tab[tid][0];
+    ltab[tid][1] = kLog2Tab[tid][1];
+  }
   const int64_t grp = blockIdx.x, ch = blockIdx.z;
   const uint32_t row0 = (uint32_t)grp * C::G;
   const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;
@@ -516,7 +521,7 @@ __global__ void __launch_bounds__(C::TH) k_pass2(RowArgs<T> a) {
       if (!QI_DBG(8)) {
         rowacc += p;
         mx = max_t(mx, p);
-        pl += plog2p(p);
+        pl += plog2p(p, ltab);
       }
     }
     plogp += (double)pl;

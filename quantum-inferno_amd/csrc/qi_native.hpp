@@ -247,6 +247,34 @@ template <typename T>
 int launch_zoom_coarse_gather(const ZoomArgs<T>& a, int64_t n_channels, hipStream_t st);
 template <typename T>
 int launch_zoom_coarse_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
+// ---- float64 zoom (qi_zoom64.hip) ------------------------------------------------------------------------------------
+constexpr int kZ64Taps = 16;       // interpolator taps (oversampling >= 4: 2.8e-12 of a unit tone)
+constexpr int kZ64MaxTile = 8192;  // panel samples per workgroup and band (= n / partial slots of the two-pass kernels)
+constexpr int kZ64Levels = 5;      // coarse grids of Lf / 64 ... Lf / 4 samples (a band is oversampled >= 4 times on its grid)
+struct Z64Args {
+  int64_t Lf, n, M;             // transform length, record length, coarse grid (M = Lf >> log2d)
+  int32_t log2d, kind;          // fine samples per coarse sample D = 1 << log2d (64 ... 4); table kind 0 / 1 / 2
+  int32_t nbands, panel_bands;  // bands of this level's list; rows of the panel
+  const BandDesc* bands;        // [nbands] device (k_lo, k_len, src_off | shift, coef, out_band)
+  const cplx<double>* X;        // [C][Lf] spectra of the records
+  const cplx<double>* Hc;       // compact bank (Gabor tables)
+  cplx<double>* Z;              // [C][nbands][M] coarse spectra, transformed in place to coarse samples
+  const double* weights;        // [D][kZ64Taps] device
+  double inv_len;
+  float two_over_len;
+  cplx<double>* coef;           // [C][panel_bands][n] or null
+  double* bits;
+  double* time_part;            // [C][chunk_total][n] per-time planes (or the output row itself when chunk_total = 1)
+  double* part_band;            // [C][panel_bands][nblk]
+  double* part_stat;            // [C][stat_stride][3]
+  int64_t nblk, stat_stride;
+  int32_t chunk_base, chunk_total;
+  double power_scale, eps;
+};
+int launch_z64_gather(const Z64Args& a, int64_t n_channels, hipStream_t st);
+int launch_z64_interp(const Z64Args& a, int nchunk, int64_t n_channels, hipStream_t st);
+void z64_weights(int log2d, double* w /*[1 << log2d][kZ64Taps]*/);
+
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 
 template <typename T>
