@@ -415,7 +415,16 @@ def main():
         step(time_stft=True)
     device_sync()
     stage_all = plan.profile_read()
-    dominant = max(stage_all.items(), key=lambda kv: kv[1][0])[0]
+    # (of the stages that PRODUCE panel rows: block, zoom, pass2, inverse -- pass 1 of the two-pass engine, the forward
+    # transform and the coarse stage write no coefficient)
+    def produces(name):
+        try:
+            sb = plan.stage_bands(name)
+        except ValueError:
+            return False
+        return sb[0] + sb[2] > 0
+    producing = {k: v for k, v in stage_all.items() if v[1] and produces(k)}
+    dominant = max((producing or stage_all).items(), key=lambda kv: kv[1][0])[0]
     # timed region: HIP events around the dominant stage's launches only, on every 7th transform call (odd, so that the
     # CWT and the Stockwell calls of a step are sampled alike) -- every event is a bubble in the stream
     plan.profile(True, stages=[dominant], period=7 if n_ch * order <= 12 else 1)

@@ -1,17 +1,18 @@
 // Zoom engine: the narrow-spectrum bands of a panel (long atoms: a few hundred to a few ten thousand occupied bins
 // out of a million) are slowly varying envelopes on a carrier.  Their occupied bins, moved to baseband, are
 // transformed on a COARSE time grid on which the band is oversampled at least 4 times (one small inverse FFT per
-// band: k_zoom_gather + k_zoom_coarse), and the panel is produced from that by band-limited interpolation -- a 12-tap
-// Kaiser-windowed sinc (beta = 14), error below 6e-7 of a unit tone at the band edge (where the spectrum is < 2^-30
-// of its peak), < 1e-9 in the bulk -- times the carrier phasor.  About 50-80 instructions per output instead of a
+// band: k_zoom_gather + k_zoom_coarse), and the panel is produced from that by band-limited interpolation -- N-tap
+// interpolators that are exact at the Chebyshev nodes of the band (10 taps at 4 x oversampling: 9e-8 of a unit tone
+// anywhere in the band; 6 and 4 taps for bands oversampled 8 and 32 times: see zoom_weights) -- times the carrier
+// phasor.  About 35-60 instructions per output instead of a
 // share of a million-point transform, nothing discarded (the zero-padded half of the linear correlation is simply not
 // evaluated), no intermediate: the kernel is bound by the panel write.
 //
 // The coarse grid has D = 64 >> level fine samples per coarse sample (level 0: the narrowest bands, D = 64; each
 // level doubles the bandwidth that can be carried).  One wave-step = 64 consecutive outputs = the 64 lanes of a wave;
-// it spans S = 1 << level coarse intervals, so its window holds 12 + S coarse samples, which are uniform over the
+// it spans S = 1 << level coarse intervals, so its window holds N + S - 1 coarse samples, which are uniform over the
 // wave (scalar registers, taken from a vector register by v_readlane as the window slides); each lane carries the
-// 12 + S weights of its own position in the window (registers; zero outside its 12 taps).  Every store is a 512-byte
+// N + S - 1 weights of its own position in the window (registers; zero outside its N taps).  Every store is a 512-byte
 // run.  Waves only meet for the per-band power sum (one barrier per band).  No MFMA: there is no dense contraction.
 #include "qi_common.hpp"
 #include "qi_device.hpp"

@@ -549,6 +549,16 @@ def test_float64_native_engine_vs_oracle(golden, order):
         res = getattr(nat, name)(x32, coef=True, reductions=True)
         check_digest(res, g, name, order, TOL_F32_RECORD[np.float64], rows)
         del res
+    if order == 3:
+        # cwt_atoms (circular CWT: the float64 zoom engine's rolled kind) on the native engine, every band against the
+        # reference's rows and against the hipFFT engine
+        c_atoms, _, _, fc = cwt_atoms.cwt_chirp_from_sig(x32[0], fs, order)
+        assert np.array_equal(fc, g["chirp_f_o3"])
+        got = c_atoms[:, torch.from_numpy(g["chirp_tsel_o3"]).cuda()].cpu().numpy()
+        refc = g["chirp_rows_o3"]
+        assert np.max(np.abs(got - refc)) / np.sqrt(float(g["chirp_pmax_o3"])) <= TOL_F32_RECORD[np.float64]["coef"]
+        del c_atoms
+        engine.clear_plans()
     # a batch of three records (tiles of the scratch) equals the single-record runs
     xb = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, 3, np.float64) for c in range(3)])).cuda()
     if order == 3:
