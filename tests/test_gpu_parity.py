@@ -856,6 +856,41 @@ def test_native_engine_other_lengths(log2n, order):
     ref.close()
 
 
+@pytest.mark.parametrize("log2n,order", [(19, 3), (19, 12), (21, 3)])
+def test_native_engine_batch_launches_other_lengths(log2n, order):
+    """Calls of four records and more use other launch geometry than single records: 8192-sample long blocks for the
+    1024-reach block bands, twelve bands per block workgroup, the 6- / 4-tap zoom classes, the gather inside the coarse
+    kernel.  At lengths other than the benchmark's: a five-record joint call against the single-record call of one of
+    its records (the other geometry of the same arithmetic) and against the hipFFT engine, every row."""
+    from quantum_inferno_amd import _lib
+
+    n, fs, C = 1 << log2n, 800.0, 5
+    rng = np.random.default_rng(100 + log2n + order)
+    x = np.stack([orc.synth_chirp(n, fs, c, C, np.float32) for c in range(C)]) + 0.1 * rng.standard_normal((C, n)).astype(np.float32)
+    x = torch.from_numpy(x).cuda()
+    nat = _plan_with_all(n, fs, order, np.float32, channels=C)
+    nb = len(nat.freq[0])
+    ref = engine.TfrPlan(n, np.float32, None, engine.TfrPlan.workspace_for(n, nb, np.float32, 1), _lib.QI_ENGINE_HIPFFT)
+    ref.set_styx_bank(order, fs)
+    ref.set_stx_bands(order, fs)
+    pick = 3
+    batch = nat.cwt_stx(x, coef=True, reductions=True)
+    one = nat.cwt_stx(x[pick : pick + 1], coef=True, reductions=True)
+    for name, b, o in (("cwt", batch[0], one[0]), ("stx", batch[1], one[1])):
+        gold = getattr(ref, name)(x[pick : pick + 1], coef=True, reductions=True)
+        peak = gold.coef[0].abs().amax(dim=1)
+        err_one = (b.coef[pick] - o.coef[0]).abs().amax(dim=1) / peak
+        err_ref = (b.coef[pick] - gold.coef[0]).abs().amax(dim=1) / peak
+        assert float(err_one.max()) <= 1e-5, (name, int(err_one.argmax()), float(err_one.max()))
+        assert float(err_ref.max()) <= 2e-5, (name, int(err_ref.argmax()), float(err_ref.max()))
+        assert torch.allclose(b.power_band[pick], gold.power_band[0], rtol=1e-4, atol=1e-9 * float(gold.power_band.max()))
+        assert torch.allclose(b.power_time[pick], gold.power_time[0], rtol=1e-3, atol=1e-6 * float(gold.power_time.max()))
+        assert torch.allclose(b.stats[pick, :3], gold.stats[0, :3], rtol=1e-4)
+        del gold
+    nat.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32), ("f64_odd", np.float64)])
 def test_shannon_1d_family_vs_reference(golden, tag, dtype):
     """1-D Shannon TDR / FFT (tfr_info.py:97-200) against the reference's outputs (tests/golden/shannon1d.npz)."""
