@@ -12,6 +12,7 @@
 namespace qi {
 
 void set_error(const char* fmt, ...);
+const char* tune_env(const char* name);  // development switch (read only when QI_TUNE is set; qi_api.hip)
 
 #define QI_HIP(call)                                                                        \
   do {                                                                                      \

@@ -44,6 +44,8 @@ __device__ __forceinline__ cplx<T> csub(cplx<T> a, cplx<T> b) {
 struct StftFusedArgs {
   int64_t n, seg, hop, nseg, lead;  // lead: zero-extended samples in front of the record (seg / 2 for the STFT, 0 Welch)
   int32_t log2g, G;                 // G = 1 << log2g segments per workgroup
+  int32_t ngroups, per_xcd;         // segment groups per record; work items (record, group) per XCD
+  int64_t nitems;                   // records x groups
   double scale, eps;
 };
 
@@ -63,7 +65,13 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   cplx<T>* __restrict__ data = reinterpret_cast<cplx<T>*>(lds_raw);
   cplx<T>* __restrict__ tw = data + (size_t)G * TILE;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  const int64_t c = blockIdx.y, m0 = (int64_t)blockIdx.x * G;
+  // XCD-aware mapping: consecutive workgroup ids go to consecutive XCDs (eight L2s), and a workgroup writes only G
+  // consecutive time samples of each frequency row (64-byte runs).  Every XCD takes a CONTIGUOUS range of the (record,
+  // segment group) items, so the runs that complete a 128-byte line come from workgroups behind the same L2, a few
+  // dispatch slots apart, and leave it as full lines.
+  const int64_t item = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= a.per_xcd || item >= a.nitems) return;
+  const int64_t c = item / a.ngroups, m0 = (item % a.ngroups) * G;
   const T* __restrict__ x = sig + c * a.n;
 
   for (int k = tid; k < M; k += kStftThreads) {
@@ -192,7 +200,9 @@ template <typename T, int LR, int LC>
 static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t nseg, StftFusedArgs a,
                              hipStream_t st) {
   const int64_t M = 1ll << (LR + LC);
-  const int G = stft_fused_group(M, LR, LC, sizeof(cplx<T>), 80 * 1024);  // two workgroups per CU
+  size_t budget = 80 * 1024;  // two workgroups per CU
+  if (const char* e = tune_env("QI_STFT_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+  const int G = stft_fused_group(M, LR, LC, sizeof(cplx<T>), budget);
   if (G < 1) {
     set_error("fused STFT: a transform of %lld points does not fit the LDS tile", (long long)(2 * M));
     return QI_ERR_UNSUPPORTED;
@@ -208,7 +218,10 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     raised = true;
   }
-  dim3 grid((unsigned)ceil_div(nseg, G), (unsigned)C);
+  a.ngroups = (int32_t)ceil_div(nseg, G);
+  a.nitems = (int64_t)a.ngroups * C;
+  a.per_xcd = (int32_t)ceil_div(a.nitems, 8);
+  dim3 grid((unsigned)(8 * a.per_xcd));
   k_stft_fused<T, LR, LC><<<grid, kStftThreads, lds, st>>>(sig, win, Z, bits, a);
   QI_LAUNCH_CHECK();
   return QI_OK;
