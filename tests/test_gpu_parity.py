@@ -571,6 +571,36 @@ def test_float64_native_engine_vs_oracle(golden, order):
     ref.close()
 
 
+@pytest.mark.parametrize("log2n,name", [(19, "cwt"), (21, "stx")])
+def test_float64_native_engine_other_lengths(log2n, name):
+    """The float64 engines run transforms of 2^20 / 2^21 points: the zero-padded styx CWT of a 2^19-sample record and the
+    Stockwell transform of a 2^21-sample record are the other two shapes they take (other tile sizes and coarse grids of the
+    float64 zoom).  Against the hipFFT engine: every row to its own maximum, and the fused reductions."""
+    from quantum_inferno_amd import _lib
+
+    n, fs, order = 1 << log2n, 1000.0, 6
+    x = torch.from_numpy(orc.synth_chirp(n, fs, dtype=np.float64)).cuda().unsqueeze(0)
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    ws = engine.TfrPlan.workspace_for(n, nb, np.float64, 1)
+    nat = engine.TfrPlan(n, np.float64, None, ws, _lib.QI_ENGINE_AUTO)
+    ref = engine.TfrPlan(n, np.float64, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        (plan.set_styx_bank if name == "cwt" else plan.set_stx_bands)(order, fs)
+    which = 0 if name == "cwt" else 2
+    assert nat.stage_bands("zoom")[which] + nat.stage_bands("pass2")[which] == nb and nat.stage_bands("zoom")[which] > 0
+    a = getattr(nat, name)(x, coef=True, reductions=True)
+    b = getattr(ref, name)(x, coef=True, reductions=True)
+    peak = b.coef[0].abs().amax(dim=1)
+    err = (a.coef[0] - b.coef[0]).abs().amax(dim=1) / peak
+    assert float(err.max()) <= 5e-9, (int(err.argmax()), float(err.max()))
+    assert float((a.coef - b.coef).abs().max()) <= TOL[np.float64]["coef"] * float(b.coef.abs().max())
+    assert torch.allclose(a.power_band, b.power_band, rtol=1e-9, atol=1e-12 * float(b.power_band.max()))
+    assert torch.allclose(a.power_time, b.power_time, rtol=1e-8, atol=1e-11 * float(b.power_time.max()))
+    assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-9)
+    nat.close()
+    ref.close()
+
+
 def test_streaming_chunks_float64():
     """Config-5 shape in miniature: a long float64 record as overlapped chunks; every chunk's reduced product equals
     the transform of that chunk alone, and a run restarted at a chunk boundary reproduces the rest."""
