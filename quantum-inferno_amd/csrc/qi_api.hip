@@ -1106,8 +1106,8 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
   for (int32_t j = 0; j < B; ++j) {
     const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
     const int64_t len = hi >= lo ? hi - lo + 1 : 0;
-    // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30
-    const double w = std::ceil(std::sqrt(30.0 * M_LN2 / h_par[j])) + 1.0;
+    // taps with |x| <= w are above 2^-30 of the atom's peak: exp(-p_re x^2) >= 2^-30 (float64: 2^-52)
+    const double w = std::ceil(std::sqrt((p->d.dtype == QI_F64 ? 52.0 : 30.0) * M_LN2 / h_par[j])) + 1.0;
     // (a band of the widest reach groups -- half of each 4096-sample block is overlap there -- goes to the zoom
     // engine instead when its spectrum fits one of its grids)
     if (can_block && block_group_of(w) > 0 &&
@@ -1123,7 +1123,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
         pk.amp = am * std::sqrt(M_PI / p_re) / (double)native::kBlk;
       }
       picks.push_back(pk);
-    } else if (can_short && zoom_class(p, bank, L, len) < 0 && !(len > 0 && len <= p->native_kmax) && w <= 8192.0 &&
+    } else if (can_short && zoom_class(p, bank, L, len) < 0 && !(len > 0 && len <= narrow_limit(p, bank, L)) && w <= 8192.0 &&
                w < (double)n / 8) {
       shorts.push_back(j);
       short_w.push_back((int32_t)w);
@@ -1891,16 +1891,34 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   const auto& t = p->nat[kind];
   const int64_t n = p->n, B = kind == 2 ? p->nb_stx : p->nb[kind], Lf = t.Lf;
   constexpr int G = 8;
-  const int64_t N1 = Lf / native::kN2, nblk = N1 / G;
   const T* sig = static_cast<const T*>(sig_v);
-  std::vector<int> nchunk;
+  // two-pass sub-tables: the table itself and, for the styx bank, its wide-spectrum short-atom bands evaluated as
+  // circular correlations of length n (table 3: half the bank row and intermediate; k_edge_fix restores the zero-padded
+  // result on their first / last samples)
+  struct Sub {
+    const qi_plan::NativeTable* t;
+    int kernel_kind;
+    int64_t N1, nblk;
+    std::vector<int> nchunk;
+  };
+  std::vector<Sub> subs;
+  subs.push_back({&t, kind, 0, 0, {}});
+  const bool shorts = kind == 0 && p->nat[3].ready && p->nedge > 0;
+  if (shorts) subs.push_back({&p->nat[3], 1, 0, 0, {}});
   int chunk_total = 0;
-  for (const auto& grp : t.groups) {
-    int nc = (int)ceil_div(p->native_wgs, nblk * C);
-    nc = nc < 1 ? 1 : (nc > grp.count ? grp.count : nc);
-    nchunk.push_back(nc);
-    chunk_total += nc;
+  int64_t imd_elems = 0;
+  for (auto& sb : subs) {
+    sb.N1 = sb.t->Lf / native::kN2;
+    sb.nblk = sb.N1 / G;
+    if ((int64_t)sb.t->imd_slots * sb.t->Lf > imd_elems) imd_elems = (int64_t)sb.t->imd_slots * sb.t->Lf;
+    for (const auto& grp : sb.t->groups) {
+      int nc = (int)ceil_div(p->native_wgs, sb.nblk * C);
+      nc = nc < 1 ? 1 : (nc > grp.count ? grp.count : nc);
+      sb.nchunk.push_back(nc);
+      chunk_total += nc;
+    }
   }
+  const int64_t nblk = subs[0].nblk;  // (the largest: the circular sub-table has half as many row groups)
   // float64 zoom bands: one launch per coarse-grid level, its bands dealt to `zchunk` workgroups per tile
   int zchunk[native::kZ64Levels] = {};
   size_t e_z = 0;  // coarse storage of the largest level (the levels run one after the other)
@@ -1917,18 +1935,23 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     return QI_ERR_STATE;
   }
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr, want_time = out->power_time != nullptr;
-  const bool time_via_part = want_time && chunk_total > 1;
-  const int64_t stat_slots = (int64_t)chunk_total * nblk;
+  const bool time_via_part = want_time && (chunk_total > 1 || shorts);
+  const int64_t nbk = nblk + (shorts ? 1 : 0);  // partial slots per band (last one: the corrected edge samples)
+  const int64_t stat_slots = (int64_t)chunk_total * nblk + (shorts ? p->nedge : 0);
   const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
-  const size_t e_imd = (size_t)t.imd_slots * Lf * sizeof(cplx<T>);
-  const size_t e_pb = (size_t)B * nblk * 8, e_ps = (size_t)stat_slots * 24;
+  const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
+  const size_t e_imd = (size_t)imd_elems * sizeof(cplx<T>);
+  const size_t e_pb = (size_t)B * nbk * 8, e_ps = (size_t)stat_slots * 24;
   const size_t e_tp = time_via_part ? (size_t)chunk_total * n * sizeof(T) : 0;
-  const size_t per_chan = e_x + e_imd + e_z + e_pb + e_ps + e_tp;
-  if (p->ws_bytes < per_chan + 8192) {
-    set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 8192);
+  const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
+  const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
+  const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
+  const size_t per_chan = e_x + e_xn + e_imd + e_z + e_pb + e_ps + e_tp + e_ep + e_et + e_ez;
+  if (p->ws_bytes < per_chan + 16384) {
+    set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 16384);
     return QI_ERR_NOMEM;
   }
-  int64_t Ct = (int64_t)((p->ws_bytes - 8192) / per_chan);
+  int64_t Ct = (int64_t)((p->ws_bytes - 16384) / per_chan);
   if (Ct > C) Ct = C;
   p->shared_valid = false;
   char* w = p->ws;
@@ -1938,59 +1961,79 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     return r;
   };
   cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
+  cplx<T>* Xn = reinterpret_cast<cplx<T>*>(carve(e_xn));
   cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
   cplx<T>* Z = reinterpret_cast<cplx<T>*>(carve(e_z));
+  char* parts0 = w;  // the partial sums: cleared per tile when the sub-tables fill different numbers of slots
   double* part_band = reinterpret_cast<double*>(carve(e_pb));
   double* part_stat = reinterpret_cast<double*>(carve(e_ps));
+  const size_t parts_bytes = (size_t)(w - parts0);
   T* time_part = reinterpret_cast<T*>(carve(e_tp));
+  T* edge_p = reinterpret_cast<T*>(carve(e_ep));
+  T* edge_time = reinterpret_cast<T*>(carve(e_et));
+  cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
+    if (shorts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.begin(st, QI_STAGE_FORWARD);
     QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
     QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    if (shorts) QI_TRY(native::launch_even_bins<T>(X, Xn, ct, n, st));
     p->prof.end(QI_STAGE_FORWARD, st);
-    native::RowArgs<T> a{};
-    a.Lf = Lf;
-    a.n = n;
-    a.N1 = N1;
-    a.N2 = native::kN2;
-    a.panel_bands = (int32_t)B;
-    a.imd_slots = t.imd_slots;
-    a.chunk_total = chunk_total;
-    a.X = X;
-    a.Hc = static_cast<const cplx<T>*>(t.Hc);
-    a.Hfull = static_cast<const cplx<T>*>(t.Hfull);
-    a.imd = imd;
-    a.inv_len = 1.0 / (double)Lf;
-    a.two_over_len = (float)(2.0 / (double)Lf);
-    a.neg_last_row = kind == 0 ? 1 : 0;
-    a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
-    a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
-    a.time_part = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
-    a.part_band = want_band ? part_band : nullptr;
-    a.part_stat = want_stat ? part_stat : nullptr;
-    a.nblk = nblk;
-    a.stat_nblk = nblk;
-    a.stat_stride = stat_slots;
-    a.power_scale = out->power_scale == 0.0 ? 1.0 : out->power_scale;
-    a.eps = out->eps == 0.0 ? 2.220446049250313e-16 : out->eps;
+    cplx<T>* coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+    T* bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+    T* tpart = !want_time ? nullptr : (time_via_part ? time_part : static_cast<T*>(out->power_time) + c0 * n);
+    const double power_scale = out->power_scale == 0.0 ? 1.0 : out->power_scale;
+    const double eps = out->eps == 0.0 ? 2.220446049250313e-16 : out->eps;
     int chunk_base = 0;
-    for (size_t g = 0; g < t.groups.size(); ++g) {
-      const auto& grp = t.groups[g];
-      a.bands = t.d_bands + grp.first;
-      a.nbands = grp.count;
-      a.gen_list = t.d_gen_list ? t.d_gen_list + grp.gen_first : nullptr;
-      a.ngen_launch = grp.ngen;
-      a.chunk_base = chunk_base;
-      if (grp.ngen > 0) {
-        p->prof.begin(st, QI_STAGE_PASS1);
-        QI_TRY(native::launch_pass1<T>(a, kind, ct, st));
-        p->prof.end(QI_STAGE_PASS1, st);
+    for (size_t si = 0; si < subs.size(); ++si) {
+      const Sub& sb = subs[si];
+      const auto& tt = *sb.t;
+      native::RowArgs<T> a{};
+      a.Lf = tt.Lf;
+      a.n = n;
+      a.N1 = sb.N1;
+      a.N2 = native::kN2;
+      a.panel_bands = (int32_t)B;
+      a.imd_slots = tt.imd_slots;
+      a.chunk_total = chunk_total;
+      a.X = si == 0 ? X : Xn;
+      a.Hc = static_cast<const cplx<T>*>(tt.Hc);
+      a.Hfull = static_cast<const cplx<T>*>(tt.Hfull);
+      a.imd = imd;
+      a.inv_len = 1.0 / (double)tt.Lf;
+      a.two_over_len = (float)(2.0 / (double)tt.Lf);
+      a.neg_last_row = sb.kernel_kind == 0 ? 1 : 0;
+      a.coef = coef;
+      a.bits = bits;
+      a.edge_z = edge_z;
+      a.edge_wmax = p->edge_wmax;
+      a.nedge = p->nedge;
+      a.time_part = tpart;
+      a.part_band = want_band ? part_band : nullptr;
+      a.part_stat = want_stat ? part_stat : nullptr;
+      a.nblk = nbk;
+      a.stat_nblk = nblk;
+      a.stat_stride = stat_slots;
+      a.power_scale = power_scale;
+      a.eps = eps;
+      for (size_t g = 0; g < tt.groups.size(); ++g) {
+        const auto& grp = tt.groups[g];
+        a.bands = tt.d_bands + grp.first;
+        a.nbands = grp.count;
+        a.gen_list = tt.d_gen_list ? tt.d_gen_list + grp.gen_first : nullptr;
+        a.ngen_launch = grp.ngen;
+        a.chunk_base = chunk_base;
+        if (grp.ngen > 0) {
+          p->prof.begin(st, QI_STAGE_PASS1);
+          QI_TRY(native::launch_pass1<T>(a, sb.kernel_kind, ct, st));
+          p->prof.end(QI_STAGE_PASS1, st);
+        }
+        p->prof.begin(st, QI_STAGE_PASS2);
+        QI_TRY(native::launch_pass2<T>(a, sb.kernel_kind, G, sb.nchunk[g], ct, st));
+        p->prof.end(QI_STAGE_PASS2, st);
+        chunk_base += sb.nchunk[g];
       }
-      p->prof.begin(st, QI_STAGE_PASS2);
-      QI_TRY(native::launch_pass2<T>(a, kind, G, nchunk[g], ct, st));
-      p->prof.end(QI_STAGE_PASS2, st);
-      chunk_base += nchunk[g];
     }
     for (int g = 0; g < native::kZ64Levels; ++g) {
       if (t.z64_count[g] == 0) continue;
@@ -2007,19 +2050,21 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.Hc = static_cast<const cplx<T>*>(t.Hc);
       z.Z = Z;
       z.weights = p->d_z64_w[g];
-      z.inv_len = a.inv_len;
-      z.two_over_len = a.two_over_len;
-      z.coef = a.coef;
-      z.bits = a.bits;
-      z.time_part = a.time_part;
-      z.part_band = a.part_band;
-      z.part_stat = a.part_stat;
+      z.inv_len = 1.0 / (double)Lf;
+      z.two_over_len = (float)(2.0 / (double)Lf);
+      z.coef = coef;
+      z.bits = bits;
+      z.time_part = tpart;
+      z.part_band = want_band ? part_band : nullptr;
+      z.part_stat = want_stat ? part_stat : nullptr;
       z.nblk = nblk;
+      z.pb_stride = nbk;
+      z.stat_nblk = nblk;
       z.stat_stride = stat_slots;
       z.chunk_base = chunk_base;
       z.chunk_total = chunk_total;
-      z.power_scale = a.power_scale;
-      z.eps = a.eps;
+      z.power_scale = power_scale;
+      z.eps = eps;
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
       QI_TRY(native::launch_z64_gather(z, ct, st));
       QI_TRY(fft_c2c<T>(p->fft, Z, z.M, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
@@ -2030,18 +2075,36 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       chunk_base += zchunk[g];
     }
     p->prof.begin(st, QI_STAGE_EPILOGUE);
+    if (shorts) {
+      native::EdgeArgs<T> e{};
+      e.bands = p->d_edge;
+      e.nedge = p->nedge;
+      e.panel_bands = (int32_t)B;
+      e.n = n;
+      e.wmax = p->edge_wmax;
+      e.stat_slots = stat_slots;
+      e.sig = sig + c0 * n;
+      e.coef = coef;
+      e.edge_z = edge_z;
+      e.bits = bits;
+      e.edge_p = edge_p;
+      e.power_scale = power_scale;
+      e.eps = eps;
+      QI_TRY(native::launch_edge<T>(e, ct, want_time ? edge_time : nullptr, want_band ? part_band : nullptr, nbk, nbk - 1,
+                                    want_stat ? part_stat : nullptr, stat_slots - p->nedge, st));
+    }
     double* pb_out = want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr;
     double* st_out = want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr;
     if (time_via_part && (want_band || want_stat)) {
-      QI_TRY(native::launch_tail<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total, nullptr, 0,
-                                    want_band ? part_band : nullptr, want_stat ? part_stat : nullptr, pb_out, st_out, B, nblk,
-                                    stat_slots, nullptr, st));
+      QI_TRY(native::launch_tail<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
+                                    shorts ? edge_time : nullptr, p->edge_wmax, want_band ? part_band : nullptr,
+                                    want_stat ? part_stat : nullptr, pb_out, st_out, B, nbk, stat_slots, nullptr, st));
     } else {
       if (time_via_part)
         QI_TRY(native::launch_time_reduce<T>(time_part, static_cast<T*>(out->power_time) + c0 * n, ct, n, chunk_total,
-                                             nullptr, 0, st));
+                                             shorts ? edge_time : nullptr, p->edge_wmax, st));
       if (want_band || want_stat)
-        QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr, pb_out, st_out, ct, B, nblk,
+        QI_TRY(launch_finalize(want_band ? part_band : nullptr, want_stat ? part_stat : nullptr, pb_out, st_out, ct, B, nbk,
                                stat_slots, st, nullptr));
     }
     p->prof.end(QI_STAGE_EPILOGUE, st);
@@ -2253,8 +2316,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     const int v = atoi(e);
     if (v >= 1 && v <= native::kZ64Levels) p->native_z64_levels = v;
   }
-  if (desc->dtype == QI_F64) {  // exact paths only: every band on the two-pass kernels, evaluated at the full length
-    p->native_zoom = p->native_block = p->native_short = p->native_split = 0;
+  if (desc->dtype == QI_F64) {  // the float32 zoom / block / split engines are sized for the float32 tolerance
+    const int short64 = p->native_short && !(tune_env("QI_NATIVE_SHORT64") && atoi(tune_env("QI_NATIVE_SHORT64")) == 0);
+    p->native_zoom = p->native_block = p->native_split = 0;
+    p->native_short = short64;  // wide-spectrum, short-atom styx bands as circular correlations of length n + edge fix
     p->native_rows = 8;
     if (p->native_group <= 0) p->native_group = 8;  // wide bands per launch group: bounds the intermediate (32 MB per band and record)
   }

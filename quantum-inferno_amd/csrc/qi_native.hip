@@ -675,7 +675,20 @@ __global__ void __launch_bounds__(256) k_edge_fix(EdgeArgs<T> a) {
   const int64_t m0 = side ? 0 : a.n - eb.w + t;
   const double x0 = (side ? (double)(1 + tloc) : (double)(-eb.w)) + 0.5;
   const int64_t chunk = (cnt + kWave - 1) / kWave;
-  if (eb.p_im == 0.0 && chunk >= 4) {
+  if constexpr (sizeof(T) == 8) {
+    // float64: every tap in double (a few hundred taps per sample at most: the bands are wide-spectrum, short atoms)
+    for (int64_t i = lane; i < cnt; i += kWave) {
+      const double x = x0 + (double)i;
+      const double ph = eb.omega * x - eb.p_im * x * x;
+      const double turns = ph * 0.15915494309189535;  // / 2 pi
+      double sn, cs;
+      sincospi(2.0 * (turns - rint(turns)), &sn, &cs);
+      const double env = eb.amp * exp(-(eb.p_re * x * x));
+      const double v = (double)sig[m0 + i] * env;
+      sr += (T)(v * cs);
+      si -= (T)(v * sn);
+    }
+  } else if (eb.p_im == 0.0 && chunk >= 4) {
     // each lane takes `chunk` consecutive taps: phasor and Gaussian envelope by recurrences from exact seeds,
     // conj(psi(x + 1)) = conj(psi(x)) e^{-i omega} e^{-p (2 x + 1)}
     const int64_t i0 = (int64_t)lane * chunk;
@@ -1094,6 +1107,7 @@ int launch_even_bins(const cplx<T>* x2, cplx<T>* x1, int64_t C, int64_t n, hipSt
   return QI_OK;
 }
 template int launch_even_bins<float>(const float2*, float2*, int64_t, int64_t, hipStream_t);
+template int launch_even_bins<double>(const double2*, double2*, int64_t, int64_t, hipStream_t);
 
 template <typename T>
 int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band, int64_t nblk, int64_t band_slot,
@@ -1109,6 +1123,8 @@ int launch_edge(const EdgeArgs<T>& a, int64_t C, T* edge_time, double* part_band
 }
 template int launch_edge<float>(const EdgeArgs<float>&, int64_t, float*, double*, int64_t, int64_t, double*, int64_t,
                                 hipStream_t);
+template int launch_edge<double>(const EdgeArgs<double>&, int64_t, double*, double*, int64_t, int64_t, double*, int64_t,
+                                 hipStream_t);
 
 int launch_band_support(const double2* F, int64_t L, int nb, double thr2, double* out, hipStream_t st) {
   k_band_support<<<nb, 256, 0, st>>>(F, L, thr2, out);

@@ -267,7 +267,8 @@ struct Z64Args {
   double* time_part;            // [C][chunk_total][n] per-time planes (or the output row itself when chunk_total = 1)
   double* part_band;            // [C][panel_bands][nblk]
   double* part_stat;            // [C][stat_stride][3]
-  int64_t nblk, stat_stride;
+  int64_t nblk, stat_stride;    // tiles per record (= partial slots a band fills); stat slots per record
+  int64_t pb_stride, stat_nblk; // partial slots per band in part_band; blocks per chunk in part_stat
   int32_t chunk_base, chunk_total;
   double power_scale, eps;
 };

@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       if (tid == 0) {
         double t = 0.0;
         for (int q = 0; q < NW; ++q) t += s_red[q];
-        a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.nblk + tile] = t;
+        a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.pb_stride + tile] = t;
       }
     }
   }
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
         s1 += s_fin[1][q];
         s2 += s_fin[2][q];
       }
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.nblk + tile) * 3;
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.stat_nblk + tile) * 3;
       o[0] = m;
       o[1] = s1;
       o[2] = s2;
