@@ -550,8 +550,8 @@ bool native_wanted(const qi_plan* p, int kind) {
   if (p->d.dtype == QI_F64) return p->native_f64 && is_pow2(p->n) && native_len_ok(Lf);
   if (is_pow2(p->n) && native_len_ok(Lf)) return true;
   // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
-  // band), and those engines take any power-of-two length from 2^18: the table build decides
-  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 18) && Lf <= (1ll << 26);
+  // band), and those engines take any power-of-two length from 2^16: the table build decides
+  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 16) && Lf <= (1ll << 26);
 }
 
 // Widest spectrum support (bins) of a band that keeps a compact bank row: the one-pass loader's limit, or -- float64 with
@@ -1029,8 +1029,11 @@ int build_block_stx(qi_plan* p, const std::vector<BlockPick>& picks, const std::
 int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
   if (!p->native_zoom || table == 3 || len <= 0 || Lf % native::kZoomD != 0) return -1;
   const int64_t M0 = Lf / native::kZoomD;
-  if (M0 % native::kBlk != 0 || !is_pow2(M0 / native::kBlk)) return -1;  // the coarse stage works in 4096-point planes
-  for (int g = 0; g < native::kZoomLevels; ++g) {
+  if (!is_pow2(M0)) return -1;
+  // the coarse stage works in 4096-point planes: a short record starts at the first grid level that fills one
+  int g_min = 0;
+  while ((M0 << g_min) < native::kBlk) ++g_min;
+  for (int g = g_min; g < native::kZoomLevels; ++g) {
     if (p->n % ((int64_t)native::kZoomD * native::zoom_steps(g) * 4) != 0) return -1;
     if (native::kZoomOversample * len <= (M0 << g)) {
       if (g > p->native_zoom_max_level) return -1;
@@ -1150,7 +1153,8 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     for (int32_t j : keep) {
       const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
       const int64_t len = hi >= lo ? hi - lo + 1 : 0;
-      if (zoom_class(p, bank, L, len) >= 0 || (len > 0 && len <= p->native_kmax)) continue;
+      // (a band the one-pass loader of the two-pass kernels would take stays there only where those kernels exist)
+      if (zoom_class(p, bank, L, len) >= 0 || (len > 0 && len <= p->native_kmax && native_len_ok(L))) continue;
       std::vector<double> part;
       QI_TRY(analyse_support(p, 0, L, B, j, 1, d_par, &part, st, (double)se));
       const int64_t tlo = (int64_t)part[1], thi = (int64_t)part[2];

@@ -73,7 +73,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
   const int64_t gw = (int64_t)blockIdx.x * NW + wv;  // wave index along time
   const uint32_t step_a = (uint32_t)gw * STEPS;      // first wave-step of this wave
   const uint32_t mmask = (uint32_t)((a.Lf / kZoomD) << GRID) - 1u, lmask = (uint32_t)a.Lf - 1u;
-  const int plog2 = ilog2((int)((a.Lf / kZoomD) / kBlk)) + GRID;  // log2 of the planes per band
+  const int plog2 = ilog2((int)(((a.Lf / kZoomD) << GRID) / kBlk));  // log2 of the planes per band
   float wgt[TAPS];
 #pragma unroll
   for (int j = 0; j < TAPS; ++j) wgt[j] = weights[j * kWave + lane];  // [tap][lane]: coalesced
