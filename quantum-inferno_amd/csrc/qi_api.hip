@@ -550,8 +550,8 @@ bool native_wanted(const qi_plan* p, int kind) {
   if (p->d.dtype == QI_F64) return p->native_f64 && is_pow2(p->n) && native_len_ok(Lf);
   if (is_pow2(p->n) && native_len_ok(Lf)) return true;
   // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
-  // band), and those engines take any power-of-two length from 2^16: the table build decides
-  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 16) && Lf <= (1ll << 26);
+  // band), and those engines take any power-of-two length from 2^15: the table build decides
+  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 15) && Lf <= (1ll << 26);
 }
 
 // Widest spectrum support (bins) of a band that keeps a compact bank row: the one-pass loader's limit, or -- float64 with
