@@ -1922,13 +1922,17 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       chunk_total += nc;
     }
   }
-  const int64_t nblk = subs[0].nblk;  // (the largest: the circular sub-table has half as many row groups)
+  // partial slots per band: the row groups of the two-pass kernels (the circular sub-table has half as many) or the tiles
+  // of the float64 zoom, whichever is more
+  const int64_t nblk_z = n / native::kZ64Tile;
+  const int64_t nblk = subs[0].nblk > nblk_z ? subs[0].nblk : nblk_z;
+  const bool clear_parts = shorts || subs[0].nblk != nblk;  // (some bands leave slots unwritten)
   // float64 zoom bands: one launch per coarse-grid level, its bands dealt to `zchunk` workgroups per tile
   int zchunk[native::kZ64Levels] = {};
   size_t e_z = 0;  // coarse storage of the largest level (the levels run one after the other)
   for (int g = 0; g < native::kZ64Levels; ++g) {
     if (t.z64_count[g] == 0) continue;
-    int nc = (int)ceil_div(p->native_wgs, nblk * C);
+    int nc = (int)ceil_div(p->native_wgs, nblk_z * C);
     zchunk[g] = nc < 1 ? 1 : (nc > t.z64_count[g] ? t.z64_count[g] : nc);
     chunk_total += zchunk[g];
     const size_t bytes = (size_t)t.z64_count[g] * (size_t)((Lf / 64) << g) * sizeof(cplx<T>);
@@ -1978,7 +1982,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   cplx<T>* edge_z = e_ez ? reinterpret_cast<cplx<T>*>(carve(e_ez)) : nullptr;
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
-    if (shorts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
+    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.begin(st, QI_STAGE_FORWARD);
     QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
     QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
@@ -2061,7 +2065,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.time_part = tpart;
       z.part_band = want_band ? part_band : nullptr;
       z.part_stat = want_stat ? part_stat : nullptr;
-      z.nblk = nblk;
+      z.nblk = nblk_z;
       z.pb_stride = nbk;
       z.stat_nblk = nblk;
       z.stat_stride = stat_slots;

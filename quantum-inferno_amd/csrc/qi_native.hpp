@@ -249,7 +249,7 @@ template <typename T>
 int launch_zoom_coarse_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 // ---- float64 zoom (qi_zoom64.hip) ------------------------------------------------------------------------------------
 constexpr int kZ64Taps = 16;       // interpolator taps (oversampling >= 4: 2.8e-12 of a unit tone)
-constexpr int kZ64MaxTile = 8192;  // panel samples per workgroup and band (= n / partial slots of the two-pass kernels)
+constexpr int kZ64Tile = 4096;     // panel samples per workgroup and band (one partial slot per band and tile)
 constexpr int kZ64Levels = 5;      // coarse grids of Lf / 64 ... Lf / 4 samples (a band is oversampled >= 4 times on its grid)
 struct Z64Args {
   int64_t Lf, n, M;             // transform length, record length, coarse grid (M = Lf >> log2d)
