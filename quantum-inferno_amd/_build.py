@@ -15,8 +15,9 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libqi_tfr.so")
 SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip", "qi_block.hip", "qi_zoom.hip", "qi_shannon1d.hip", "qi_stft_sliding.hip", "qi_stft_fused.hip", "qi_zoom64.hip"]
 ARCH = "gfx950"
-# the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950)
-PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize",), "qi_zoom.hip": ("-fno-slp-vectorize",)}
+# the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950);
+# -fno-signed-zeros lets the zero halves of half-spectrum bands fold out of the first butterfly layer (x + 0 -> x)
+PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize", "-fno-signed-zeros"), "qi_zoom.hip": ("-fno-slp-vectorize",)}
 
 
 def torch_lib_dir():
