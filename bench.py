@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU leg (0: min(16, cores))")
     ap.add_argument("--engine", default="auto", choices=["auto", "hipfft", "native"])
     ap.add_argument("--workspace-gib", type=float, default=0.0, help="plan scratch (0: sized from the batch, <= 48 GiB)")
+    ap.add_argument("--two-streams", type=int, default=1,
+                    help="1: after the timed region also report the steps issued alternately on two streams (calls of one or two records, N = 1)")
     ap.add_argument("--wrappers", type=int, default=1,
                     help="1: also time the reference-signature wrappers NumPy in -> NumPy out (config 1 shape, one GPU)")
     ap.add_argument("--stub", type=int, default=0,
@@ -556,6 +558,36 @@ def main():
             qengine.NUMPY_RESULT_DTYPE = "reference"
             qengine.clear_plans()
             line["numpy_wrappers"] = out_w
+        if world == 1 and not stub and args.two_streams and n_ch <= 2 and stft is None and args.dtype == "f32":
+            # Calls of one or two records: a fifth of the step are short launches (forward transform, coarse stage, tail)
+            # that leave most of the chip idle.  A caller that has independent records to transform hides them by
+            # alternating two plans on two streams (no cross-stream events inside a step) -- reported beside `value`,
+            # never as `value`: the kernels' durations stretch while they share the chip, so the roofline above would
+            # not describe them.
+            plans2 = [plan, qi.TfrPlan(n, tdtype, dev, ws, engine_code)]
+            plans2[1].set_styx_bank(order, fs)
+            plans2[1].set_stx_bands(order, fs)
+            streams2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            outs2 = [outs[0], plans2[1].cwt_stx(sig, coef=True, reductions=True)]
+            torch.cuda.synchronize()
+
+            def run2(k):
+                for i in range(k):
+                    j = i & 1
+                    with torch.cuda.stream(streams2[j]):
+                        plans2[j].cwt_stx(sig, out=outs2[j])
+            run2(200)
+            torch.cuda.synchronize()
+            k2 = 1000
+            t2 = time.perf_counter()
+            run2(k2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            line["two_streams"] = {"steps": k2, "ms_per_step": round(dt2 / k2 * 1e3, 4),
+                                   "value": round(points_step * k2 / dt2 / 1e6, 1),
+                                   "note": "the same steps issued alternately on two streams (two plans, two sets of buffers): the "
+                                           "short launches of one step run under the long launches of the other"}
+            plans2[1].close()
         if cpu:
             line["cpu_baseline"] = cpu
         if stub:
