@@ -10,6 +10,6 @@ from . import scales_dyadic  # noqa: F401  (host tables; importable without a GP
 from . import utilities  # noqa: F401
 from . import _lib, engine  # noqa: F401
 from . import styx_fft, styx_cwt, styx_stx, cwt_atoms, tfr_info  # noqa: F401
-from .engine import TfrPlan, TfrResult  # noqa: F401
+from .engine import PlanRing, TfrPlan, TfrResult  # noqa: F401
 
 __version__ = "0.1.0"

@@ -808,6 +808,32 @@ def test_fused_cwt_stx_call_matches_separate_calls():
     plan.close()
 
 
+def test_plan_ring_matches_single_plan():
+    """PlanRing: independent records on alternating plans / streams give the results of one plan on one stream, bit for
+    bit, and every result carries the event that follows its launches."""
+    n, fs, order = 1 << 18, 1000.0, 3
+    recs = [torch.from_numpy(orc.synth_chirp(n, fs, c, 5, np.float32)).cuda().unsqueeze(0) for c in range(5)]
+    plan = _plan_with_all(n, fs, order, np.float32)
+    want = []
+    for r in recs:
+        c, s = plan.cwt_stx(r, coef=True, reductions=True)
+        want.append((c.coef.clone(), s.coef.clone(), c.reduced.clone(), s.reduced.clone()))
+    plan.close()
+    ring = qi.PlanRing(n, torch.float32, setup=lambda p: (p.set_styx_bank(order, fs), p.set_stx_bands(order, fs)), depth=2)
+    for i, r in enumerate(recs):
+        c, s, done = ring.cwt_stx(r, coef=True, reductions=True)
+        done.synchronize()
+        assert torch.equal(c.coef, want[i][0]) and torch.equal(s.coef, want[i][1]), i
+        assert torch.equal(c.reduced, want[i][2]) and torch.equal(s.reduced, want[i][3]), i
+    # two calls in flight: both slots' results are intact after their events
+    c0, s0, d0 = ring.cwt_stx(recs[0], coef=True, reductions=True)
+    c1, s1, d1 = ring.cwt_stx(recs[1], coef=True, reductions=True)
+    d0.synchronize()
+    d1.synchronize()
+    assert torch.equal(c0.coef, want[0][0]) and torch.equal(s1.coef, want[1][1])
+    ring.close()
+
+
 def test_fused_call_other_requests_and_tiles():
     """qi_cwt_stx beyond the benchmark's request: reductions only and coefficients + bits through the joint launches
     (the reductions do not depend on which panels are stored: bit-equal), the two transforms asking for different
