@@ -186,6 +186,27 @@ def gen_stft():
     save("stft.npz", **d)
 
 
+def gen_stft_large():
+    """The STFT of configs[2]: 2^20 samples @ 1000 Hz, order 12 (2048-sample segments, 1025 x 1025 bins): sampled rows and
+    columns of the reference's panel and bits for a float32 and a float64 record, the axes and the panel maximum."""
+    n, fs, order = 1 << 20, 1000.0, 12
+    d = {}
+    for dtype in (np.float32, np.float64):
+        tag = np.dtype(dtype).name
+        sig = synth_chirp(n, fs, dtype=dtype)
+        z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
+        rows = np.unique(np.concatenate([np.arange(0, z.shape[0], 64), [1, z.shape[0] - 2, z.shape[0] - 1]]))
+        cols = np.unique(np.concatenate([np.arange(0, z.shape[1], 64), [1, z.shape[1] - 2, z.shape[1] - 1]]))
+        d[f"rows_{tag}"], d[f"cols_{tag}"] = rows, cols
+        d[f"z_rows_{tag}"], d[f"z_cols_{tag}"] = z[rows], z[:, cols]
+        d[f"bits_rows_{tag}"], d[f"bits_cols_{tag}"] = bits[rows], bits[:, cols]
+        d[f"zmax_{tag}"] = np.abs(z).max()
+        d[f"shape_{tag}"] = np.array(z.shape)
+        d[f"t_{tag}"], d[f"f_{tag}"] = t, f
+        d[f"sig_samples_{tag}"] = sig[:: n // 4096]
+    save("stft_n1048576_o12.npz", **d)
+
+
 def time_samples(n, dense=False):
     """Time samples kept of a long panel row: a regular comb, the middle of the record and -- `dense` (the benchmark
     length, every band kept) -- both record ends (zero padding / wrap-around act there) and a few samples around
@@ -336,6 +357,8 @@ if __name__ == "__main__":
         gen_small()
     if "stft" in todo:
         gen_stft()
+    if "stftlarge" in todo:
+        gen_stft_large()
     if "stxgen" in todo:
         gen_stx_general()
     if "shannon1d" in todo:

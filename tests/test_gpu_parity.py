@@ -103,6 +103,26 @@ def test_stft_vs_reference(golden, tag, dtype, order):
     check_bits(bits[:, ::step], gz, tol)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_stft_benchmark_shape_vs_reference(golden, dtype):
+    """The STFT of BASELINE configs[2] (2^20 samples, order 12, 2048-sample segments: the fused kernel's <5,5> shape)
+    against sampled rows and columns of the reference's 1025 x 1025 panel, axes bit-exact."""
+    g = golden("stft_n1048576_o12.npz")
+    n, fs, order = 1 << 20, 1000.0, 12
+    sig = orc.synth_chirp(n, fs, dtype=np.dtype(dtype).type)
+    assert np.array_equal(sig[:: n // 4096], g[f"sig_samples_{dtype}"])  # the fixture's record
+    z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
+    assert np.array_equal(np.array(z.shape), g[f"shape_{dtype}"])
+    assert np.array_equal(t, g[f"t_{dtype}"]) and np.array_equal(f, g[f"f_{dtype}"])
+    rows, cols = g[f"rows_{dtype}"], g[f"cols_{dtype}"]
+    tol = 2e-6 if dtype == "float32" else 1e-12
+    zmax = float(g[f"zmax_{dtype}"])
+    assert np.max(np.abs(z[rows] - g[f"z_rows_{dtype}"])) <= tol * zmax
+    assert np.max(np.abs(z[:, cols] - g[f"z_cols_{dtype}"])) <= tol * zmax
+    big = np.abs(g[f"z_cols_{dtype}"]) >= 1e-3 * zmax
+    assert np.max(np.abs(bits[:, cols] - g[f"bits_cols_{dtype}"])[big]) <= (2e-3 if dtype == "float32" else 1e-8)
+
+
 def test_stft_2d_batch_and_errors(golden):
     g = golden("stft.npz")
     f, t, z = styx_fft.stft_complex_pow2(g["sig_2d"], 1000.0, 256)

@@ -115,6 +115,22 @@ def test_stft(golden, tag, dtype, order):
     assert np.allclose(bits[:, ::step], g[f"bits_{key}"], rtol=0, atol=1e-5 if tag.startswith("n16") else 0)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_stft_benchmark_shape(golden, dtype):
+    """The STFT of BASELINE configs[2] (2^20 samples, order 12: 1025 x 1025 bins) against sampled rows and columns of the
+    reference's panel."""
+    g = golden("stft_n1048576_o12.npz")
+    n, fs, order = 1 << 20, 1000.0, 12
+    sig = orc.synth_chirp(n, fs, dtype=np.dtype(dtype).type)
+    assert np.array_equal(sig[:: n // 4096], g[f"sig_samples_{dtype}"])
+    z, bits, t, f = orc.stft_from_sig(sig, fs, order)
+    assert np.array_equal(np.array(z.shape), g[f"shape_{dtype}"])
+    assert np.array_equal(t, g[f"t_{dtype}"]) and np.array_equal(f, g[f"f_{dtype}"])
+    rows, cols = g[f"rows_{dtype}"], g[f"cols_{dtype}"]
+    assert np.array_equal(z[rows], g[f"z_rows_{dtype}"]) and np.array_equal(z[:, cols], g[f"z_cols_{dtype}"])
+    assert np.allclose(bits[rows], g[f"bits_rows_{dtype}"], rtol=0, atol=1e-5)
+
+
 def test_stft_2d_tukey_quarter(golden):
     g = golden("stft.npz")
     f, t, z = orc.stft_complex_pow2(g["sig_2d"], 1000.0, 256)
