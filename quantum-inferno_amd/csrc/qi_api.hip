@@ -1036,7 +1036,9 @@ int zoom_class(const qi_plan* p, int table, int64_t Lf, int64_t len) {
   for (int g = g_min; g < native::kZoomLevels; ++g) {
     if (p->n % ((int64_t)native::kZoomD * native::zoom_steps(g) * 4) != 0) return -1;
     if (native::kZoomOversample * len <= (M0 << g)) {
-      if (g > p->native_zoom_max_level) return -1;
+      // (the finest grid costs more in the coarse stage than the two-pass kernels save -- where those exist; at other
+      // lengths it keeps the table off the hipFFT engine)
+      if (g > p->native_zoom_max_level && native_len_ok(Lf)) return -1;
       // on the coarsest grid the band may be oversampled far more than 4 times: shorter interpolators (classes 5, 6)
       if (g == 0 && p->native_zoom_short) {
         if ((int64_t)native::zoom_design_oversampling(6) * len <= M0) return 6;

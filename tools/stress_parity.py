@@ -7,13 +7,16 @@ sys.path.insert(0, ROOT)
 from quantum_inferno_amd import engine, _lib, scales_dyadic, synth
 
 bad = 0
-cases = [(o, l, c) for o in (1, 2, 4, 8, 24) for l in (15, 17, 19, 20) for c in (1, 5)] + [(3, 22, 1), (12, 22, 1), (5, 21, 4)]
+import os as _os
+cases = [(o, l, c) for o in (1, 2, 4, 8, 24) for l in (15, 17, 19, 20) for c in (1, 5)] + [(3, 22, 1), (12, 22, 1), (5, 21, 4), (1, 22, 1), (2, 21, 2), (1.5, 18, 1), (0.75, 16, 1)]
+if _os.environ.get("QI_STRESS_CASES"):
+    cases = [tuple(float(v) if "." in v else int(v) for v in c.split(":")) for c in _os.environ["QI_STRESS_CASES"].split(",")]
 for order, log2n, C in cases:
     n, fs = 1 << log2n, 800.0
     if order == 24 and log2n > 19:
         continue
     nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
-    rng = np.random.default_rng(order * 100 + log2n)
+    rng = np.random.default_rng(int(order * 100) + log2n)
     x = np.stack([synth.log_chirp(n, fs, c, C, np.float32) for c in range(C)]) + 0.2 * rng.standard_normal((C, n)).astype(np.float32)
     x = torch.from_numpy(x).cuda()
     nat = engine.TfrPlan(n, torch.float32, None, engine.TfrPlan.workspace_for(n, nb, torch.float32, C), _lib.QI_ENGINE_AUTO)
@@ -35,7 +38,7 @@ for order, log2n, C in cases:
                 bad += 1
                 print(f"  FAIL {name} order {order} n 2^{log2n} C {C} record {c}: row {int(err.argmax())} err {float(err.max()):.2e} band-power {pb:.2e}")
             del b
-    print(f"order {order:2d} n 2^{log2n} C {C}: bands {nb}, native bands {native}, worst row-rel cwt {worst['cwt']:.1e} stx {worst['stx']:.1e}", flush=True)
+    print(f"order {order:4g} n 2^{log2n} C {C}: bands {nb}, native bands {native}, worst row-rel cwt {worst['cwt']:.1e} stx {worst['stx']:.1e}", flush=True)
     nat.close(); ref.close(); del a_c, a_s, x
     torch.cuda.empty_cache()
 print("failures:", bad)
