@@ -15,9 +15,8 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libqi_tfr.so")
 SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip", "qi_block.hip", "qi_zoom.hip", "qi_shannon1d.hip", "qi_stft_sliding.hip", "qi_stft_fused.hip", "qi_zoom64.hip"]
 ARCH = "gfx950"
-# the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950);
-# -fno-signed-zeros lets the zero halves of half-spectrum bands fold out of the first butterfly layer (x + 0 -> x)
-PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize", "-fno-signed-zeros"), "qi_zoom.hip": ("-fno-slp-vectorize",)}
+# the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950)
+PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize",), "qi_zoom.hip": ("-fno-slp-vectorize",)}
 
 
 def torch_lib_dir():
@@ -33,7 +32,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "qi_tfr.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    deps += [os.path.join(ROOT, "include", "qi_tfr.h"), os.path.abspath(__file__)]  # (the flags live in this file)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
