@@ -390,7 +390,7 @@ struct qi_plan {
   int native_blk_maxwq = 4;    // reach groups above this one (1, 2, 4) prefer the zoom engine when their spectrum fits it
   int native_blk_bands = 6;    // bands one block workgroup walks at most (each workgroup pays one forward transform)
   int native_blk_bands_batch = 12;  // the same for batches of native_blk_batch_from records or more (item cut 1)
-  int native_blk_batch_from = 4;
+  int native_blk_batch_from = 0;    // 0: 4 records, 8 for tables with few block bands (batch_from())
   native::EdgeBand* d_edge = nullptr;  // short-atom bands of table 3
   int32_t nedge = 0;
   int64_t edge_wmax = 0;
@@ -560,6 +560,16 @@ bool native_wanted(const qi_plan* p, int kind) {
 bool z64_table(const qi_plan* p, int table) { return p->d.dtype == QI_F64 && p->native_z64 && table != 3; }
 int64_t narrow_limit(const qi_plan* p, int table, int64_t Lf) {
   return z64_table(p, table) ? std::max<int64_t>(p->native_kmax, Lf >> (9 - p->native_z64_levels)) : p->native_kmax;
+}
+
+// Records per call from which the block launches use their batch geometry (12 bands per workgroup, long blocks): fewer
+// forward transforms and per-time planes against fewer, heavier workgroups.  Measured on one box: with the 18 block bands
+// of an order-3 table the batch geometry pays from 8 records (+2 % at 4 and 6 records without it), with the 35 / 46 of
+// orders 6 / 12 from 4 (+2-3 % with it).  The same answer for both tables of a joint call.
+int batch_from(const qi_plan* p) {
+  if (p->native_blk_batch_from > 0) return p->native_blk_batch_from;
+  const int32_t rows = std::max(p->blk[0].ready ? p->blk[0].rows : 0, p->blk[2].ready ? p->blk[2].rows : 0);
+  return rows <= 24 ? 8 : 4;
 }
 
 // Order the bands into launch groups: the wide bands are dealt out `native_group` per group (all in one group when
@@ -1378,7 +1388,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   // block engine launches (one per reach group): their chunks come after the pass-2 chunks
   const auto& bt = p->blk[kind];
   const bool blocks = kind != 1 && bt.ready;
-  const int cut = C >= p->native_blk_batch_from ? 1 : 0;  // (both halves of a joint tile see the same C)
+  const int cut = C >= batch_from(p) ? 1 : 0;  // (both halves of a joint tile see the same C and the same tables)
   const auto& il = bt.var[cut];
   const int chunk_p2 = chunk_total;
   int64_t blk_stats = 0, blk_slots = 0;

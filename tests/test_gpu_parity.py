@@ -934,13 +934,14 @@ def test_native_engine_other_lengths(log2n, order):
 
 @pytest.mark.parametrize("log2n,order", [(19, 3), (19, 12), (21, 3)])
 def test_native_engine_batch_launches_other_lengths(log2n, order):
-    """Calls of four records and more use other launch geometry than single records: 8192-sample long blocks for the
+    """Calls of four (order 3: eight) records and more use other launch geometry than single records: 8192-sample long blocks for the
     1024-reach block bands, twelve bands per block workgroup, the 6- / 4-tap zoom classes, the gather inside the coarse
     kernel.  At lengths other than the benchmark's: a five-record joint call against the single-record call of one of
     its records (the other geometry of the same arithmetic) and against the hipFFT engine, every row."""
     from quantum_inferno_amd import _lib
 
-    n, fs, C = 1 << log2n, 800.0, 5
+    n, fs = 1 << log2n, 800.0
+    C = 9 if order == 3 else 5  # (the batch geometry starts at 8 records for the few block bands of an order-3 table, at 4 otherwise)
     rng = np.random.default_rng(100 + log2n + order)
     x = np.stack([orc.synth_chirp(n, fs, c, C, np.float32) for c in range(C)]) + 0.1 * rng.standard_normal((C, n)).astype(np.float32)
     x = torch.from_numpy(x).cuda()
