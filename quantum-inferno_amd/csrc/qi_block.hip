@@ -999,7 +999,7 @@ __device__ __forceinline__ void zoom_coarse_plane(cplx<T>* __restrict__ plane0) 
 }
 // The same with the gather step inside: the plane's 4096 inputs are formed in registers (zoom_gather_value) instead of
 // being written by a gather launch and read back -- one launch and two passes over the coarse storage fewer.
-template <typename T, bool STX>
+template <typename T, bool STX, int NF>
 __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, const uint32_t plane_i,
                                                          cplx<T>* __restrict__ buf, cplx<T>* __restrict__ tw256) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
   const int64_t ch = blockIdx.z;
   const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);
   cplx<T> v[16];
-  zoom_gather16<T, STX>(a, bd, tau1, col, X, v);
+  zoom_gather16<T, STX, NF>(a, bd, tau1, col, X, v);
   {
     float s, c;
     sincospif((float)tid * (2.0f / 256.0f), &s, &c);
@@ -1026,18 +1026,18 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
 #pragma unroll
   for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
 }
-template <typename T>
+template <typename T, int NF>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse2g(ZoomArgs<T> a0, ZoomArgs<T> a2) {
   __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
-  if (blockIdx.x < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false>(a0, blockIdx.x, buf, tw256);
-  else zoom_coarse_plane_gather<T, true>(a2, blockIdx.x - (uint32_t)a0.planes, buf, tw256);
+  if (blockIdx.x < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false, NF>(a0, blockIdx.x, buf, tw256);
+  else zoom_coarse_plane_gather<T, true, NF>(a2, blockIdx.x - (uint32_t)a0.planes, buf, tw256);
 }
 template <typename T, bool STX>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse_g(ZoomArgs<T> a) {
   __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
-  zoom_coarse_plane_gather<T, STX>(a, blockIdx.x, buf, tw256);
+  zoom_coarse_plane_gather<T, STX, 8>(a, blockIdx.x, buf, tw256);
 }
 
 template <typename T>
@@ -1270,7 +1270,9 @@ int launch_zoom_coarse_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<
     return QI_ERR_STATE;
   }
   dim3 grid((unsigned)(a0.planes + a2.planes), 1, (unsigned)n_channels);
-  k_zoom_coarse2g<float><<<grid, kBlkThreads, 0, st>>>(a0, a2);
+  // few records: a couple of workgroups per CU, each waiting on its loads -- twice as many in flight
+  if (n_channels <= 2) k_zoom_coarse2g<float, 16><<<grid, kBlkThreads, 0, st>>>(a0, a2);
+  else k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

@@ -54,7 +54,7 @@ __device__ __forceinline__ cplx<T> zoom_gather_value(const ZoomArgs<T>& a, const
 // thread that walks its sixteen values one after the other waits sixteen times for memory), the block twiddle
 // exp(2 pi i r tau1 / P) by a recurrence over the terms from two seeds (the sixteen first bins of a thread lie in at most
 // two 4096-bin blocks of the grid), and the outer twiddle exp(2 pi i kappa0 tau1 / M) by binary powers from two seeds.
-template <typename T, bool STX>
+template <typename T, bool STX, int NF = 8>  // NF: loads in flight per thread (8 or 16)
 __device__ __forceinline__ void zoom_gather16(const ZoomArgs<T>& a, const BandDesc& bd, const uint32_t tau1, const int col,
                                               const cplx<T>* __restrict__ X, cplx<T> (&v)[16]) {
   const int32_t M = (int32_t)((a.Lf / kZoomD) << bd.edge_slot), P = M / kBlk;
@@ -80,11 +80,12 @@ __device__ __forceinline__ void zoom_gather16(const ZoomArgs<T>& a, const BandDe
   const uint32_t base_mod = (uint32_t)ks_lo & ((uint32_t)M - 1u);
   for (int m = 0; m < nterm; ++m) {
 #pragma unroll
-    for (int hb = 0; hb < 16; hb += 8) {  // eight loads in flight at a time (sixteen cost a wave per SIMD in registers)
-      cplx<T> x[8], h[8];
-      bool on[8];
+    for (int hb = 0; hb < 16; hb += NF) {  // NF loads in flight at a time (sixteen cost a wave per SIMD in registers:
+                                           // taken only by calls of few records, whose few workgroups wait on latency)
+      cplx<T> x[NF], h[NF];
+      bool on[NF];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NF; ++q) {
         const int b = hb + q;
         const int32_t ks = ks0[b] + kBlk * m;
         on[q] = ks < ks_hi;
@@ -101,7 +102,7 @@ __device__ __forceinline__ void zoom_gather16(const ZoomArgs<T>& a, const BandDe
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < NF; ++q) {
         const int b = hb + q;
         if (!on[q]) continue;
         cplx<T> y;
