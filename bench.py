@@ -46,7 +46,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="index into BASELINE.json configs; default: configs[1] as `value` plus the configs[2] and float64 legs "
+                         "under their own keys (one rank), configs[3] = 64 records per GPU (N ranks)")
+    ap.add_argument("--legs", default="", help="comma list of the default run's legs to keep (main, configs2, f64, configs1_per_gpu)")
     ap.add_argument("--settle-ms", type=float, default=3000.0,
                     help="after the warmup steps, keep stepping (untimed) until this much wall time has passed since "
                          "their start: the GPU leaves its idle clocks only after ~0.1 s of load, and a GPU phase of a few "
@@ -58,7 +61,7 @@ def parse():
     ap.add_argument("--fs", type=float, default=None)
     ap.add_argument("--dtype", default=None, choices=["f32", "f64"])
     ap.add_argument("--stream", type=int, default=None, help="1: records streamed from the host in overlapped chunks (config 4)")
-    ap.add_argument("--stream-chunks", type=int, default=6, help="chunks of the streaming sample (a 24 h record has 131)")
+    ap.add_argument("--stream-chunks", type=int, default=35, help="chunks of the streaming sample (a 24 h record has 131)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="processes of the all-cores CPU leg (0: min(16, cores))")
     ap.add_argument("--engine", default="auto", choices=["auto", "hipfft", "native"])
@@ -72,19 +75,7 @@ def parse():
                          "writes rank- and step-dependent reduced products; everything else -- sharding, message buffers, the "
                          "pipelined gather, the barriers and the max-over-ranks timing, the JSON line -- is the real code")
     ap.add_argument("--stub-dump", default="", help="with --stub: rank 0 saves the last gathered buffers here (torch.save)")
-    a = ap.parse_args()
-    cfg = CONFIGS[a.config]
-    for k, v in cfg.items():
-        if getattr(a, k) is None:
-            setattr(a, k, v)
-    a.fs = 1000.0 if a.fs is None else a.fs
-    a.dtype = a.dtype or "f32"
-    a.stream = a.stream or 0
-    if a.steps is None:
-        a.steps = 200 if a.channels * a.order <= 12 else 20
-    if a.warmup is None:
-        a.warmup = 20 if a.channels * a.order <= 12 else 3
-    return a
+    return ap.parse_args()
 
 
 def required_bytes(n_ch, n_b, n, real_bytes):
@@ -158,17 +149,36 @@ def cpu_baseline(args, n, fs, order):
     }
 
 
-def stream_bench(args, world, rank, local, cpu):
+class OwnedRecords:
+    """[channels, samples] record set of which this process only materialises the rows it will stream (the 24 h job is
+    566 GB: no rank holds it all).  Rows outside [first, first + count) raise -- a rank that touched one would have taken
+    an item that is not its own."""
+
+    def __init__(self, shape, first, rows):
+        self.shape, self.ndim, self.dtype = tuple(shape), 2, rows.dtype
+        self.first, self.rows = first, rows
+
+    def __getitem__(self, key):
+        ch, tm = key
+        lo, hi = ch.start - self.first, ch.stop - self.first
+        if lo < 0 or hi > self.rows.shape[0]:
+            raise IndexError(f"channels {ch.start}:{ch.stop} are not owned by this rank ({self.first}:{self.first + self.rows.shape[0]})")
+        return self.rows[lo:hi, tm]
+
+
+def stream_bench(args, ctx, cpu):
     """BASELINE configs[4] as a bounded sample: float64 records on the host, overlapped chunks, the double-buffered
-    pipeline of quantum_inferno_amd.stream (pinned staging + copy stream), reduced products only, items sharded over the
-    ranks.  One step = one (channel block, chunk) item: CWT + STX + entropy of `channels` records of 2^20 samples."""
+    pipeline of quantum_inferno_amd.stream (pinned staging + copy stream), reduced products only.  The record set is
+    `world` blocks of `channels` records; its (block, chunk) items are dealt to the ranks by `stream.rank_items` -- the
+    24 h job's sharding -- so every rank streams `chunks` items.  One step = one item: CWT + STX + entropy of `channels`
+    records of 2^20 samples."""
     import torch
     import torch.distributed as dist
 
     import quantum_inferno_amd as qi
-    from quantum_inferno_amd import dist as qdist, stream, synth
+    from quantum_inferno_amd import stream, synth
 
-    dev = torch.device("cuda", local)
+    world, rank, dev, stub = ctx.world, ctx.rank, ctx.dev, ctx.stub
     n, fs, order = 1 << args.log2n, args.fs, args.order
     hop = n // 2
     tdtype = torch.float32 if args.dtype == "f32" else torch.float64
@@ -176,89 +186,113 @@ def stream_bench(args, world, rank, local, cpu):
     real_bytes = 4 if args.dtype == "f32" else 8
     n_ch = args.channels
     n_b = len(qi.scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
-    chunks = max(args.stream_chunks, args.warmup + 2)
+    warm_req = 3 if args.warmup is None else args.warmup
+    chunks = max(args.stream_chunks, warm_req + 2)
     total = n + (chunks - 1) * hop
-    # every rank streams its own block of records (weak scaling: the 24 h job has 128 channels x 131 chunks per GPU)
-    host = np.empty((n_ch, total), dtype=npd)
+    # this rank's block of the record set (weak scaling: the 24 h job has 128 channels x 131 chunks per GPU)
+    rows = np.empty((n_ch, total), dtype=npd)
     base = synth.log_chirp(n, fs, rank, max(world, 1), npd)
     rng = np.random.default_rng(1000 + rank)
+    reps = -(-total // n)
+    noise = 0.01 * rng.standard_normal(total + 7919 * n_ch).astype(npd)
     for c in range(n_ch):
-        reps = -(-total // n)
-        host[c] = np.tile(np.roll(base, 7919 * c), reps)[:total] + 0.01 * rng.standard_normal(total)
-    plan = qi.TfrPlan(n, tdtype, dev, qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=32 << 30))
-    plan.set_styx_bank(order, fs)
-    plan.set_stx_bands(order, fs)
+        rows[c] = np.tile(np.roll(base, 7919 * c), reps)[:total] + noise[7919 * c : 7919 * c + total]
+    host = OwnedRecords((n_ch * world, total), n_ch * rank, rows)
+    if stub:
+        plan = StubPlan(n, n_b, rank, dtype=tdtype)
+    else:
+        plan = qi.TfrPlan(n, tdtype, dev, qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=32 << 30))
+        plan.set_styx_bank(order, fs)
+        plan.set_stx_bands(order, fs)
     pipe = stream.StreamPipeline(plan, host, hop, block=n_ch, transforms=("cwt", "stx"), keep_time=False)
-    items = len(pipe.items)
-    warm = min(args.warmup, items - 1)
-    it = pipe.run()
+    mine = stream.rank_items(pipe.items, rank, world)
+    items = len(mine)
+    warm = min(warm_req, items - 1)
+    it = pipe.run(rank=rank, world=world)
     for _ in range(warm):
         next(it)
-    torch.cuda.synchronize()
+    ctx.sync()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    done, entropy = 0, 0.0
+    done, entropy, seen = 0, 0.0, []
     for item in it:
         entropy += float(item.cwt.stats[0, 1])  # (touch the result: the item is complete)
+        seen.append((item.first_channel, item.chunk))
         done += 1
-    torch.cuda.synchronize()
+    ctx.sync()
     if world > 1:
         dist.barrier()
     dt_local = time.perf_counter() - t0
     rank_dt = [dt_local]
+    rank_items_done = [done]
     dt = dt_local
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, float(done)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
-        rank_dt = [float(v.item()) for v in every]
+        rank_dt = [float(v[0].item()) for v in every]
+        rank_items_done = [int(v[1].item()) for v in every]
         dt = max(rank_dt)
+    if stub and args.stub_dump:
+        torch.save({"rank": rank, "items": mine, "timed": seen, "warm": warm}, f"{args.stub_dump}.rank{rank}")
+    line = None
     if rank == 0:
         points_item = 2 * n_ch * n_b * n
-        value = points_item * done * world / dt / 1e6
-        # plain host -> device copy rate of one item (pinned), for the PCIe share of a step
-        x = torch.empty((n_ch, n), dtype=tdtype).pin_memory()
-        d = torch.empty((n_ch, n), dtype=tdtype, device=dev)
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        for _ in range(5):
-            d.copy_(x, non_blocking=True)
-        torch.cuda.synchronize()
-        h2d_ms = (time.perf_counter() - tc) / 5 * 1e3
+        value = points_item * sum(rank_items_done) / dt / 1e6
+        h2d_ms = None
+        if not stub:  # plain host -> device copy rate of one item (pinned), for the PCIe share of a step
+            x = torch.empty((n_ch, n), dtype=tdtype).pin_memory()
+            d = torch.empty((n_ch, n), dtype=tdtype, device=dev)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(5):
+                d.copy_(x, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d_ms = round((time.perf_counter() - tc) / 5 * 1e3, 3)
+            del x, d
         full_items = 128 * 131 / n_ch  # items one GPU of eight owns in the 24 h x 1024-channel job at this block size
         line = {
             "metric": "TFR Mpoints/sec (CWT+STX+entropy)", "value": round(value, 1), "unit": "Mpoints/s", "n_gpus": world,
             "steps": done, "warmup": warm, "ms_per_step": round(dt / max(done, 1) * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if not stub else "stub (no transform ran)",
             "config": {
                 "workload": f"BASELINE configs[4] (bounded sample): float64 records streamed from the host, chunks of 2^{args.log2n} "
                             f"samples with a hop of 2^{args.log2n - 1} @ {fs:g} Hz, order N={order:g}, CWT+STX+entropy ({n_b} bands), "
                             f"reduced products only; {n_ch} records x {items} chunks per GPU here, 128 x 131 in the 24 h job",
-                "channels_per_gpu": n_ch, "n": n, "bands": n_b, "points_per_step": points_item * world, "world_size": world,
-                "rank_seconds": [round(v, 6) for v in rank_dt],
-                "h2d_ms_per_item": round(h2d_ms, 3),
+                "channels_per_gpu": n_ch, "n": n, "bands": n_b, "points_per_step": points_item * world,
+                "world_size": dist.get_world_size() if world > 1 else 1, "backend": ctx.backend,
+                "rank_seconds": [round(v, 6) for v in rank_dt], "rank_items": rank_items_done,
+                "h2d_ms_per_item": h2d_ms,
                 "projected_seconds_24h_1024ch_8gpu": round(full_items * dt / max(done, 1), 1),
+                "projection_note": f"arithmetic: {full_items:g} items per GPU x the measured seconds per item over {done} timed items",
             },
             "step_roofline": {
                 "required_bytes_per_step": int(2 * (n_ch * n * real_bytes + n_ch * (n_b + n) * real_bytes)),
-                "note": "no panel is stored in streaming mode: the required HBM bytes are the records and the marginals only; "
-                        "the step is bound by the float64 two-pass kernels (see --dtype f64 for their stage breakdown)",
+                "note": "no panel is stored in streaming mode: the required HBM bytes are the records and the marginals only "
+                        "(see the f64 leg / --dtype f64 for the stage breakdown of the float64 engines)",
             },
         }
         if cpu:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
     plan.close()
-    if world > 1:
-        dist.destroy_process_group()
+    del pipe, plan, rows, host
+    if not stub:
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+    return line
 
 
 class StubPlan:
     """Stand-in for TfrPlan in --stub runs: no kernel, deterministic reduced products on the CPU."""
 
-    def __init__(self, n, n_b, rank):
+    def __init__(self, n, n_b, rank, dtype=None):
+        import torch
+
         self.n, self.n_b, self.rank, self.calls = n, n_b, rank, 0
+        self.rdtype, self.device = dtype or torch.float32, torch.device("cpu")
 
     def cwt_stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
         import torch
@@ -270,7 +304,8 @@ class StubPlan:
             out = []
             for k in range(2):
                 r = TfrResult(frequency_hz=np.arange(self.n_b))
-                r.reduced = reduced_out[k] if reduced_out else torch.empty(qdist.reduced_slots(n_ch, self.n_b, self.n, sig.dtype), dtype=torch.float64)
+                r.reduced = reduced_out[k] if reduced_out and reduced_out[k] is not None else torch.empty(
+                    qdist.reduced_slots(n_ch, self.n_b, self.n, sig.dtype), dtype=torch.float64)
                 o1 = r.reduced.numel() - n_ch * (self.n_b + 4)
                 o2 = o1 + n_ch * self.n_b
                 r.power_time = r.reduced[:o1].view(sig.dtype)[: n_ch * self.n].view(n_ch, self.n)
@@ -298,48 +333,97 @@ class StubPlan:
         pass
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    n, fs, order = 1 << args.log2n, args.fs, args.order
-    cpu = None
-    if world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(args, n, fs, order)
+class Ctx:
+    """What every leg of one bench run shares: the rank layout, the device and the process group."""
 
+    def __init__(self, world, rank, local, dev, stub, backend):
+        self.world, self.rank, self.local, self.dev, self.stub, self.backend = world, rank, local, dev, stub, backend
+
+    def sync(self):
+        if not self.stub:
+            import torch
+
+            torch.cuda.synchronize()
+
+
+def leg_args(args, config, **over):
+    """The arguments of one leg: BASELINE config `config` with the command line's overrides, then `over`."""
+    a = argparse.Namespace(**vars(args))
+    a.config = config
+    for k, v in CONFIGS[config].items():
+        if getattr(a, k, None) is None:
+            setattr(a, k, v)
+    for k, v in over.items():
+        setattr(a, k, v)
+    a.fs = 1000.0 if a.fs is None else a.fs
+    a.dtype = a.dtype or "f32"
+    a.stream = a.stream or 0
+    small = a.channels * a.order <= 12
+    if a.steps is None:
+        a.steps = 200 if small else 20
+    if a.warmup is None:
+        a.warmup = 20 if small else 3
+    return a
+
+
+def fit_workspace(a, ctx, n, n_b, tdtype, real_bytes, depth):
+    """Plan scratch for this leg, checked against the free HBM of this rank BEFORE anything is allocated: the two complex
+    panels, the message buffers, rank 0's receive buffers (`depth` x world x message) and the STFT outputs are fixed
+    costs; the scratch takes what is asked for (<= 48 GiB) or what is left -- fewer records per tile, never a failed
+    allocation in the middle of the first multi-GPU run.  Returns (workspace bytes, budget dict)."""
+    import torch
+
+    import quantum_inferno_amd as qi
+    from quantum_inferno_amd import dist as qdist
+
+    n_ch = a.channels
+    want = int(a.workspace_gib * 2 ** 30) if a.workspace_gib > 0 else qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=48 << 30)
+    if ctx.stub:
+        return want, {}
+    free, total = torch.cuda.mem_get_info(ctx.dev)
+    msg = 2 * qdist.reduced_slots(n_ch, n_b, n, tdtype) * 8
+    panels = 2 * n_ch * n_b * n * 2 * real_bytes
+    recv = depth * ctx.world * msg if (ctx.world > 1 and ctx.rank == 0) else 0
+    stft = 0
+    if a.stft:
+        seg = 2048 if a.order >= 12 else 512  # (an upper bound is enough here)
+        stft = int(n_ch * (seg // 2 + 1) * (n // (seg // 2) + 2) * 3 * real_bytes)
+    fixed = panels + depth * msg + recv + stft + n_ch * n * real_bytes + (6 << 30)  # + bank tables, allocator slack
+    room = free - fixed
+    per_rec = qi.TfrPlan.workspace_for(n, n_b, tdtype, 1, cap_bytes=0)
+    budget = {"free_hbm_bytes": int(free), "panels_bytes": int(panels), "messages_bytes": int(depth * msg), "receive_bytes": int(recv),
+              "scratch_bytes": int(want)}
+    if room < per_rec:
+        raise RuntimeError(f"rank {ctx.rank}: {n_ch} records x {n_b} bands x 2^{a.log2n} need {fixed / 2**30:.1f} GiB + scratch, "
+                           f"{free / 2**30:.1f} GiB are free: lower --channels")
+    if want > room:
+        want = int(room)
+        budget["scratch_bytes"] = want
+        budget["note"] = "scratch cut to the free HBM: the records pass in more tiles"
+    return want, budget
+
+
+def run_leg(a, ctx, cpu, extras=True):
+    """One timed leg.  Returns the JSON record (rank 0) or None."""
     import torch
     import torch.distributed as dist
-
-    stub = bool(args.stub)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if stub:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if stub:
-        dev = torch.device("cpu")
-        device_sync = lambda: None  # noqa: E731
-    else:
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
-        device_sync = torch.cuda.synchronize
 
     import quantum_inferno_amd as qi
     from quantum_inferno_amd import _lib, dist as qdist, styx_fft, synth
 
-    if args.stream:
-        return stream_bench(args, world, rank, local, cpu)
-    tdtype = torch.float32 if args.dtype == "f32" else torch.float64
-    real_bytes = 4 if args.dtype == "f32" else 8
-    n_ch = args.channels
+    world, rank, dev, stub = ctx.world, ctx.rank, ctx.dev, ctx.stub
+    device_sync = ctx.sync
+    n, fs, order = 1 << a.log2n, a.fs, a.order
+    tdtype = torch.float32 if a.dtype == "f32" else torch.float64
+    real_bytes = 4 if a.dtype == "f32" else 8
+    n_ch = a.channels
     total_ch = n_ch * world
     first, _ = qdist.shard(total_ch, rank, world)
     bands = qi.scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
     n_b = len(bands)
-    engine_code = {"auto": _lib.QI_ENGINE_AUTO, "hipfft": _lib.QI_ENGINE_HIPFFT, "native": _lib.QI_ENGINE_NATIVE}[args.engine]
-    ws = int(args.workspace_gib * 2 ** 30) if args.workspace_gib > 0 else qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=48 << 30)
+    engine_code = {"auto": _lib.QI_ENGINE_AUTO, "hipfft": _lib.QI_ENGINE_HIPFFT, "native": _lib.QI_ENGINE_NATIVE}[a.engine]
+    depth = 2 if world > 1 else 1
+    ws, budget = fit_workspace(a, ctx, n, n_b, tdtype, real_bytes, depth)
     if stub:
         plan = StubPlan(n, n_b, rank)
         sig = torch.zeros((n_ch, n), dtype=tdtype)
@@ -349,20 +433,20 @@ def main():
         plan.set_styx_bank(order, fs)
         plan.set_stx_bands(order, fs)
         sig = torch.from_numpy(synth.channels(n, fs, first, n_ch, total_ch, np.float32 if tdtype == torch.float32 else np.float64)).to(dev)
-        stft = styx_fft.StftPlan(n, n_ch, fs, order, tdtype, dev) if args.stft else None
+        stft = styx_fft.StftPlan(n, n_ch, fs, order, tdtype, dev) if a.stft else None
 
     # the reduced products of both transforms live in one buffer: the message of the gather, no packing copy.  With more
     # than one rank the gather of step k overlaps the transforms of step k + 1 (two sets of outputs, used in turn); the
-    # complex panels themselves are written in place every step (one set: 2 x 89.7 GB at config 2).
+    # complex panels themselves are written in place every step (one set: 2 x 89.7 GB at configs[2] / [3]).
     slots = qdist.reduced_slots(n_ch, n_b, n, tdtype)
-    depth = 2 if world > 1 else 1
     messages = [torch.empty(2 * slots, dtype=torch.float64, device=dev) for _ in range(depth)]
     outs = [plan.cwt_stx(sig, coef=True, reductions=True, reduced_out=(messages[0][:slots], messages[0][slots:]))]
     for m in messages[1:]:  # further message buffers share the panels of the first set
         oc, os_ = plan.cwt_stx(sig, coef=False, reductions=True, reduced_out=(m[:slots], m[slots:]))
         oc.coef, os_.coef = outs[0][0].coef, outs[0][1].coef  # (None in a --stub run)
         outs.append((oc, os_))
-    pipe = qdist.GatherPipeline(depth=depth, dst=0)
+    small = n_ch * order <= 12  # a step of a quarter of a millisecond: every recorded event shows
+    pipe = qdist.GatherPipeline(depth=depth, dst=0, timing=world > 1 and not small)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if not stub else None
     stft_ms = []
 
@@ -395,13 +479,13 @@ def main():
         device_sync()
 
     t_warm = time.perf_counter()
-    for _ in range(args.warmup):
+    for _ in range(a.warmup):
         step()
-    # a step of config 1 is a third of a millisecond: a few warmup steps end long before the clocks have left idle
+    # a step of configs[1] is a quarter of a millisecond: a few warmup steps end long before the clocks have left idle
     settle_steps = 0
     while True:
         device_sync()
-        done = (time.perf_counter() - t_warm) * 1e3 >= args.settle_ms
+        done = (time.perf_counter() - t_warm) * 1e3 >= a.settle_ms
         if world > 1:  # every rank runs the same number of steps (each step ends in a collective)
             flag = torch.tensor([1.0 if done else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -417,6 +501,7 @@ def main():
         step(time_stft=True)
     device_sync()
     stage_all = plan.profile_read()
+
     # (of the stages that PRODUCE panel rows: block, zoom, pass2, inverse -- pass 1 of the two-pass engine, the forward
     # transform and the coarse stage write no coefficient)
     def produces(name):
@@ -425,14 +510,18 @@ def main():
         except ValueError:
             return False
         return sb[0] + sb[2] > 0
+
     producing = {k: v for k, v in stage_all.items() if v[1] and produces(k)}
     dominant = max((producing or stage_all).items(), key=lambda kv: kv[1][0])[0]
     # timed region: HIP events around the dominant stage's launches only, on every 7th transform call (odd, so that the
-    # CWT and the Stockwell calls of a step are sampled alike) -- every event is a bubble in the stream
-    plan.profile(True, stages=[dominant], period=7 if n_ch * order <= 12 else 1)
+    # CWT and the Stockwell calls of a step are sampled alike) -- every event is a bubble in the stream.  A step of many
+    # records is tens of milliseconds: there every producing stage is timed on every call.
+    timed_stages = [dominant] if small else (list(producing) or [dominant])
+    plan.profile(True, stages=timed_stages, period=7 if small else 1)
+    pipe.reset_timing()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(a.steps):
         step()
     fence()
     dt_local = time.perf_counter() - t0
@@ -440,33 +529,53 @@ def main():
     stage = plan.profile_read()
     plan.profile(False)
     rank_dt = [dt_local]
+    wait_ms = [pipe.wait_ms() / max(a.steps, 1)]
+    n_ranks = 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        n_ranks = dist.get_world_size()
+        t = torch.tensor([dt, wait_ms[0]], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
-        rank_dt = [float(v.item()) for v in every]
+        rank_dt = [float(v[0].item()) for v in every]
+        wait_ms = [float(v[1].item()) for v in every]
         dt = max(rank_dt)
 
+    line = None
     if rank == 0:
         points_step = 2 * total_ch * n_b * n
-        value = points_step * args.steps / dt / 1e6
-        name, (ms, launches) = dominant, stage[dominant]
-        per_launch_ms = ms / max(launches, 1)
-        launches_per_step = max(stage_all[dominant][1] / 3, 1)  # launches of that stage per step
-        # algorithmic bytes of that stage: the complex coefficients of the bands it produces, written once (SURVEY s8d:
-        # C*B*n*s_c), plus the per-time / per-band marginals it leaves behind
-        sb = plan.stage_bands(name)
-        stage_bands = sb[0] + sb[2]  # styx CWT + Stockwell panels of one step
-        alg_kernel_step = n_ch * stage_bands * n * 2 * real_bytes + 2 * n_ch * n * real_bytes + n_ch * stage_bands * real_bytes
-        alg_per_launch = alg_kernel_step / launches_per_step
-        achieved = alg_per_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        traffic = None
+        value = points_step * a.steps / dt / 1e6
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        tdata = {}
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"{name}:{args.dtype}:n{args.log2n}:o{order:g}:c{n_ch}")
+                tdata = json.load(open(tfile))
             except Exception:
-                traffic = None
+                tdata = {}
+
+        def stage_roofline(name):
+            """Algorithmic bytes of a stage -- the complex coefficients of the bands it produces, written once (SURVEY
+            s8d: C*B*n*s_c), plus the per-time / per-band marginals it leaves behind -- per launch over the mean launch
+            duration: from the timed region when the stage was timed there, else from the three untimed steps."""
+            timed = name in timed_stages and stage[name][1] > 0
+            ms, launches = stage[name] if timed else stage_all[name]
+            per_launch_ms = ms / max(launches, 1)
+            launches_per_step = max(stage_all[name][1] / 3, 1)
+            sb = plan.stage_bands(name)
+            nb_stage = sb[0] + sb[2]  # styx CWT + Stockwell panels of one step
+            alg_step = n_ch * nb_stage * n * 2 * real_bytes + 2 * n_ch * n * real_bytes + n_ch * nb_stage * real_bytes
+            alg_launch = alg_step / launches_per_step
+            achieved = alg_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+            traffic = tdata.get(f"{name}:{a.dtype}:n{a.log2n}:o{order:g}:c{n_ch}")
+            return {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (tdata.get("source", "profiles/traffic.json") + " (rocprofv3 --pmc passes of this command kept "
+                                   "under profiles/, not collected in this run)") if traffic is not None else None,
+                "launch_ms": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
+                "algorithmic_bytes_per_launch": int(alg_launch), "bands_per_step": nb_stage,
+                "timed_in": "timed region (HIP events)" if timed else "3 untimed steps after the warmup (HIP events)",
+            }
+
         dev_ms = sum(v[0] for v in stage_all.values()) / 3
         req = 2 * required_bytes(n_ch, n_b, n, real_bytes)
         stft_info = None
@@ -481,47 +590,42 @@ def main():
                 "frac": round(stft_alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if s_ms > 0 else None,
             }
             dev_ms += s_ms
-        wall_ms = dt / args.steps * 1e3
-        cfg_name = f"BASELINE configs[{args.config}]"
-        if (n_ch, order, bool(args.stft)) != (CONFIGS[args.config]["channels"], CONFIGS[args.config]["order"], bool(CONFIGS[args.config]["stft"])):
+        wall_ms = dt / a.steps * 1e3
+        base = CONFIGS[a.config]
+        cfg_name = f"BASELINE configs[{a.config}]"
+        if (n_ch, order, bool(a.stft), a.dtype) != (base["channels"], base["order"], bool(base["stft"]), base.get("dtype", "f32")):
             cfg_name += " (modified)"
+        if world > 1 and a.config == 2 and "(modified)" not in cfg_name:
+            cfg_name = f"BASELINE configs[3] ({total_ch} channels sharded over {world} GPUs = configs[2] per GPU)"
         line = {
             "metric": "TFR Mpoints/sec (CWT+STX+entropy)",
             "value": round(value, 1),
             "unit": "Mpoints/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": a.steps,
+            "warmup": a.warmup,
             "settle_steps": settle_steps,
             "ms_per_step": round(wall_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": a.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{cfg_name}: {n_ch} channel(s) per GPU x 2^{args.log2n} samples @ {fs:g} Hz, "
+                "workload": f"{cfg_name}: {n_ch} channel(s) per GPU x 2^{a.log2n} samples @ {fs:g} Hz, "
                             f"order N={order:g}, {'STFT+' if stft is not None else ''}CWT+STX+entropy, {n_b} bands",
                 "channels_per_gpu": n_ch,
                 "n": n,
                 "bands": n_b,
                 "points_per_step": points_step,
-                "engine": args.engine,
-                "world_size": world,
+                "engine": a.engine,
+                "world_size": n_ranks,
+                "backend": ctx.backend,
                 "rank_seconds": [round(v, 6) for v in rank_dt],
+                "gather_wait_ms_per_step": [round(v, 4) for v in wait_ms] if pipe.timing else None,
+                "gather_message_bytes_per_rank": int(2 * slots * 8) if world > 1 else 0,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": name,
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "launch_ms": round(per_launch_ms, 4),
-                "algorithmic_bytes_per_launch": int(alg_per_launch),
-                "bands_per_step": stage_bands,
-            },
+            "roofline": stage_roofline(dominant),
             "step_roofline": {
                 "required_bytes_per_step": int(req),
                 "wall_ms_per_step": round(wall_ms, 4),
@@ -535,9 +639,14 @@ def main():
                         "survey_bytes adds SURVEY s8(d)'s atom-bank read, which this engine never performs",
             },
         }
+        others = [k for k in producing if k != dominant]
+        if others:
+            line["stage_rooflines"] = {k: stage_roofline(k) for k in others}
+        if budget:
+            line["config"]["hbm_budget"] = budget
         if stft_info:
             line["stft"] = stft_info
-        if world == 1 and not stub and args.wrappers and n_ch == 1:
+        if extras and world == 1 and not stub and a.wrappers and n_ch == 1:
             # the drop-in call as the tutorials make it (s04_tone_tfr.py:84-99): NumPy in, NumPy out, one transform per
             # call -- host <-> device copies and the widening to the reference's complex128 included (never `value`)
             from quantum_inferno_amd import engine as qengine, styx_cwt, styx_stx
@@ -558,7 +667,7 @@ def main():
             qengine.NUMPY_RESULT_DTYPE = "reference"
             qengine.clear_plans()
             line["numpy_wrappers"] = out_w
-        if world == 1 and not stub and args.two_streams and n_ch <= 2 and stft is None and args.dtype == "f32":
+        if extras and world == 1 and not stub and a.two_streams and n_ch <= 2 and stft is None and a.dtype == "f32":
             # Calls of one or two records: a fifth of the step are short launches (forward transform, coarse stage, tail)
             # that leave most of the chip idle.  A caller that has independent records to transform hides them by
             # alternating two plans on two streams (no cross-stream events inside a step) -- reported beside `value`,
@@ -588,15 +697,96 @@ def main():
                                    "note": "the same steps issued alternately on two streams (two plans, two sets of buffers): the "
                                            "short launches of one step run under the long launches of the other"}
             plans2[1].close()
+            del plans2, outs2
         if cpu:
             line["cpu_baseline"] = cpu
         if stub:
             line["data"] = "stub (CPU rehearsal of the rank plumbing, no transform ran)"
-            if args.stub_dump:
+            if a.stub_dump:
                 gathered = [g.clone() if g is not None else None for g in last_gathered] if world > 1 else [qdist.pack_reduced(list(outs[0])).unsqueeze(0)]
-                torch.save({"gathered": gathered, "slots": slots, "n_ch": n_ch, "n_b": n_b, "n": n, "calls": plan.calls}, args.stub_dump)
-        print(json.dumps(line), flush=True)
+                torch.save({"gathered": gathered, "slots": slots, "n_ch": n_ch, "n_b": n_b, "n": n, "calls": plan.calls}, a.stub_dump)
     plan.close()
+    # hand every buffer of this leg back before the next one sizes itself (configs[2] holds 2 x 89.7 GB of panels)
+    del outs, messages, sig, stft, plan, pipe, last_gathered
+    qdist.clear_gather_buffers()
+    if not stub:
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+    return line
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    shaped = any(getattr(args, k) is not None for k in ("channels", "order", "stft", "dtype", "stream"))
+    composite = args.config is None and not shaped
+    # The legs of this run.  No --config and no shape flag:
+    #   one rank   -> `value` = BASELINE configs[1] (the config the metric is quoted on at one GPU), and in the same process,
+    #                 under their own keys, configs[2] (64 records x order 12, the full stack) and a float64 leg;
+    #   N ranks    -> `value` = configs[3]: configs[2]'s 64 records per GPU, sharded, one gather of the reduced product per
+    #                 step; the one-record-per-GPU latency case rides along as `configs1_per_gpu`.
+    if not composite:
+        legs = [("", leg_args(args, args.config or 1), args.cpu_seconds)]
+    elif world == 1:
+        legs = [("", leg_args(args, 1), args.cpu_seconds),
+                ("configs2", leg_args(args, 2), min(args.cpu_seconds, 12.0)),
+                ("f64", leg_args(args, 2, channels=4, dtype="f64", stft=0), min(args.cpu_seconds, 9.0))]
+    else:
+        legs = [("", leg_args(args, 2), 0.0), ("configs1_per_gpu", leg_args(args, 1), 0.0)]
+    if args.legs:
+        keep = set(args.legs.split(","))
+        legs = [l for l in legs if (l[0] or "main") in keep]
+    # CPU baselines first: the forked workers must exist before anything initialises the GPU
+    cpus = []
+    for key, a, budget in legs:
+        if world == 1 and budget > 0 and not a.stub:
+            a_cpu = argparse.Namespace(**vars(a))
+            a_cpu.cpu_seconds = budget
+            cpus.append(cpu_baseline(a_cpu, 1 << a.log2n, a.fs, a.order))
+        else:
+            cpus.append(None)
+
+    import torch
+    import torch.distributed as dist
+
+    stub = bool(args.stub)
+    backend = "none"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = dist.get_backend() + (" (RCCL over xGMI)" if not stub else "")
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    ctx = Ctx(world, rank, local, dev, stub, backend)
+
+    line = None
+    for (key, a, _), cpu in zip(legs, cpus):
+        if a.stream:
+            rec = stream_bench(a, ctx, cpu)
+        else:
+            rec = run_leg(a, ctx, cpu, extras=(key == ""))
+        if rank == 0:
+            if line is None:
+                line = rec
+                if key:
+                    line["leg"] = key
+            else:
+                line[key] = rec
+    if rank == 0:
+        if composite and world > 1:
+            line["scaling_note"] = ("weak scaling of BASELINE configs[3] (64 records per GPU): the one-GPU point of this curve is the "
+                                    "`configs2` record of the N = 1 line (whose `value` is configs[1], one record)")
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -74,6 +74,11 @@ __host__ __device__ inline C cmul(C a, C b) {
   return r;
 }
 
+// Allow kernel `fn` `bytes` of dynamic LDS on the CURRENT device.  hipFuncSetAttribute acts on the current device's
+// function object only, so the raised limits are kept per (device, function); a request above what the device offers
+// returns QI_ERR_UNSUPPORTED instead of a launch error (qi_kernels.hip).
+int allow_dynamic_lds(const void* fn, size_t bytes);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int64_t next_pow2(int64_t v) {

@@ -1,6 +1,9 @@
 // Hand-written gfx950 kernels around the FFT passes: packing, Gabor bank construction,
 // spectrum multiply, Stockwell shift x Gaussian, crop / power / entropy epilogue, STFT framing,
 // tfr_info reductions.  Wave = 64 lanes everywhere.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "qi_common.hpp"
 #include "qi_device.hpp"
 #include "qi_finalize.hpp"
@@ -441,6 +444,32 @@ __global__ void k_widen(const float* __restrict__ in, double* __restrict__ out, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = (double)in[i];
 }
+int allow_dynamic_lds(const void* fn, size_t bytes) {
+  if (bytes <= 48 * 1024) return QI_OK;  // inside every kernel's default limit
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> raised;  // (device, function) -> limit set so far
+  static std::map<int, size_t> device_max;
+  int dev = 0;
+  QI_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto dm = device_max.find(dev);
+  if (dm == device_max.end()) {
+    int v = 0;
+    QI_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    dm = device_max.emplace(dev, (size_t)v).first;
+  }
+  if (bytes > dm->second) {
+    set_error("a kernel asks for %zu bytes of LDS, device %d offers %zu per workgroup", bytes, dev, dm->second);
+    return QI_ERR_UNSUPPORTED;
+  }
+  size_t& have = raised[{dev, fn}];
+  if (bytes > have) {
+    QI_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
+  return QI_OK;
+}
+
 int launch_widen(const float* in, double* out, int64_t count, hipStream_t st) {
   int64_t blocks = ceil_div(count, 256);
   if (blocks > 16384) blocks = 16384;

@@ -887,13 +887,8 @@ __global__ void k_copy_window(const double2* __restrict__ F, cplx<T>* __restrict
 
 
 template <class Kern, typename T>
-static int launch_lds(Kern kern, bool* configured, size_t lds, const RowArgs<T>& a, dim3 grid, int threads,
-                      hipStream_t st) {
-  if (!*configured) {
-    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
-    *configured = true;
-  }
+static int launch_lds(Kern kern, size_t lds, const RowArgs<T>& a, dim3 grid, int threads, hipStream_t st) {
+  QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   kern<<<grid, threads, lds, st>>>(a);
   QI_LAUNCH_CHECK();
   return QI_OK;
@@ -901,13 +896,11 @@ static int launch_lds(Kern kern, bool* configured, size_t lds, const RowArgs<T>&
 
 template <typename T, class C, int SRC, int NPH>
 static int launch_p1(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
-  static bool configured = false;
-  return launch_lds(k_pass1<T, C, SRC, NPH>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
+  return launch_lds(k_pass1<T, C, SRC, NPH>, C::LDS_BYTES, a, grid, C::TH, st);
 }
 template <typename T, class C, int KIND, bool COEF, bool BITS>
 static int launch_p2v(const RowArgs<T>& a, dim3 grid, hipStream_t st) {
-  static bool configured = false;
-  return launch_lds(k_pass2<T, C, KIND, COEF, BITS>, &configured, C::LDS_BYTES, a, grid, C::TH, st);
+  return launch_lds(k_pass2<T, C, KIND, COEF, BITS>, C::LDS_BYTES, a, grid, C::TH, st);
 }
 // the optional outputs are compile-time variants: no per-sample branches in the epilogue
 template <typename T, class C, int KIND>
@@ -956,13 +949,8 @@ static int launch_forward_cfg(const RowArgs<float>& a0, float2* Xout, int64_t n_
     set_error("native forward transform supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
     return QI_ERR_UNSUPPORTED;
   }
-  static bool configured = false;
   auto kern = k_fwd2<float, C2>;
-  if (!configured) {
-    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)C2::LDS_BYTES));
-    configured = true;
-  }
+  QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), C2::LDS_BYTES));
   dim3 g2((unsigned)(a.N1 / C2::G), 1, (unsigned)n_channels);
   kern<<<g2, C2::TH, C2::LDS_BYTES, st>>>(a, Xout);
   QI_LAUNCH_CHECK();

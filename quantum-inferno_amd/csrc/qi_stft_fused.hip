@@ -212,12 +212,7 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
   while ((1 << a.log2g) < G) ++a.log2g;
   const size_t tile = ((size_t)1 << LR) * (((size_t)1 << LC) + 1) + 1;
   const size_t lds = ((size_t)G * tile + M) * sizeof(cplx<T>);
-  static bool raised = false;  // per instantiation: allow more than the default 64 KB of dynamic LDS once
-  if (!raised && lds > 48 * 1024) {
-    QI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    raised = true;
-  }
+  QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>), lds));
   a.ngroups = (int32_t)ceil_div(nseg, G);
   a.nitems = (int64_t)a.ngroups * C;
   a.per_xcd = (int32_t)ceil_div(a.nitems, 8);

@@ -88,6 +88,16 @@ def gather_reduced(flat, dst=0, group=None, async_op=False, slot=0):
     return (out, work) if async_op else out
 
 
+def clear_gather_buffers():
+    """Free rank 0's receive buffers (they are kept between calls; a caller that changes shape wants the memory back)."""
+    _GATHER_BUFFERS.clear()
+
+
+def receive_bytes(message_slots, world, depth=2):
+    """HBM that `depth` receive buffers of a `world`-rank gather take on the destination rank."""
+    return depth * world * message_slots * 8
+
+
 class GatherPipeline:
     """The gather of step k overlaps the transforms of step k + 1: `depth` message buffers are used in turn, and a
     buffer's gather is waited for (on the stream, not the host, with RCCL) just before the buffer is written again.
@@ -100,18 +110,46 @@ class GatherPipeline:
         gathered = pipe.drain()           # list of the receive buffers on `dst` (None elsewhere)
     """
 
-    def __init__(self, depth=2, dst=0, group=None):
+    def __init__(self, depth=2, dst=0, group=None, timing=False):
         self.depth, self.dst, self.group = depth, dst, group
         self.works = [None] * depth
         self.outs = [None] * depth
         self.k = 0
+        # timing: how long the compute stream stood still in `acquire` waiting for a gather (an event pair around the
+        # stream-side wait on a GPU, the host clock with gloo) -- what a scaling run needs to attribute a shortfall
+        self.timing = timing
+        self._pairs, self._host_wait = [], 0.0
 
     def acquire(self):
         i = self.k % self.depth
         if self.works[i] is not None:
-            self.works[i].wait()
+            self._wait(self.works[i])
             self.works[i] = None
         return i
+
+    def _wait(self, work):
+        if not self.timing:
+            work.wait()
+            return
+        if torch.cuda.is_available() and dist.get_backend(self.group) == "nccl":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            work.wait()  # (a wait of the current stream on the collective's stream, not of the host)
+            b.record()
+            self._pairs.append((a, b))
+        else:
+            import time
+
+            t0 = time.perf_counter()
+            work.wait()
+            self._host_wait += time.perf_counter() - t0
+
+    def reset_timing(self):
+        self._pairs, self._host_wait = [], 0.0
+
+    def wait_ms(self):
+        """Total milliseconds the consumer waited for gathers since `reset_timing` (call after a device sync)."""
+        return self._host_wait * 1e3 + sum(a.elapsed_time(b) for a, b in self._pairs)
 
     def submit(self, i, flat):
         self.outs[i], self.works[i] = gather_reduced(flat, self.dst, self.group, async_op=True, slot=i)
@@ -121,6 +159,6 @@ class GatherPipeline:
     def drain(self):
         for i, w in enumerate(self.works):
             if w is not None:
-                w.wait()
+                self._wait(w)
                 self.works[i] = None
         return self.outs

@@ -66,6 +66,21 @@ def as_signal(sig, device=None, dtype=None):
     return t.contiguous(), was_numpy, was_1d
 
 
+def _log2_rows(x, eps=0.0):
+    """log2(x + eps) of a [C, count] real device tensor through the library (qi_log2_offset) -- the small marginals too:
+    PyTorch computes nothing on the path."""
+    lib = _lib.require_gpu()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        _lib.check(lib.qi_log2_offset(_lib.QI_F64 if x.dtype == torch.float64 else _lib.QI_F32, x.device.index, _lib.ptr(x),
+                                      _lib.ptr(out), x.shape[0], x.numel() // x.shape[0], float(eps), None,
+                                      _lib.stream_ptr(x.device)))
+    return out
+
+
 @dataclass
 class TfrResult:
     """Outputs of one transform call; every field is a device tensor or None."""
@@ -93,16 +108,16 @@ class TfrResult:
         H = log2 S - (sum P log2 P) / S (tfr_info.py:203-236 without materialising the panel; the
         reference's eps64 inside the log changes H by < 1e-8 bits)."""
         s = self.stats[:, 1]
-        return torch.log2(s) - self.stats[:, 2] / s
+        return _log2_rows(self.stats[:, 1:2])[:, 0] - self.stats[:, 2] / s
 
     def power_per_band_bits(self):
         """log2(sum_t P + eps) - max   (tfr_info.py:93)."""
-        b = torch.log2(self.power_band + float(scales.EPSILON64))
+        b = _log2_rows(self.power_band, float(scales.EPSILON64))
         return b - b.max(dim=1, keepdim=True).values
 
     def power_per_time_bits(self):
         """log2(sum_j P + eps) - max   (tfr_info.py:91)."""
-        b = torch.log2(self.power_time.to(torch.float64) + float(scales.EPSILON64))
+        b = _log2_rows(self.power_time.to(torch.float64), float(scales.EPSILON64))
         return b - b.max(dim=1, keepdim=True).values
 
 
@@ -332,7 +347,8 @@ class PlanRing:
             ...                                      # done.synchronize() / stream.wait_event(done) before reading
 
     Results of a slot are overwritten `depth` calls later (they are the slot's `out=` buffers): consume or copy them
-    before then.  `record` must not be modified before `done` either."""
+    before then.  `record` must not be modified before `done` either; it may be dropped (its memory is tied to the
+    slot's stream with `record_stream`)."""
 
     def __init__(self, n, dtype=torch.float32, device=None, workspace_bytes=None, setup=None, depth=2,
                  engine=_lib.QI_ENGINE_AUTO, wait_input=True):
@@ -354,6 +370,8 @@ class PlanRing:
         if self.wait_input:  # the record was produced on the caller's stream
             stream.wait_stream(torch.cuda.current_stream(self.plans[j].device))
         key = (name, tuple(sig.shape), tuple(sorted(kw.items())))
+        if sig.is_cuda:
+            sig.record_stream(stream)  # the caller may drop the record: its memory is not reused before this stream is done
         with torch.cuda.stream(stream):
             res = getattr(self.plans[j], name)(sig, out=self._outs[j].get(key), **kw)
             self._outs[j][key] = res
@@ -412,6 +430,8 @@ def gabor_atoms(n, p_re, p_im, omega, amp, device=None, x=None):
     keep = [_lib.darr(a) for a in (p_re, p_im, omega, amp)]
     out = torch.empty((len(keep[0][0]), n), dtype=torch.complex128, device=dev)
     if x is not None:
+        if np.shape(x) != (n,):
+            raise ValueError(f"x must hold the {n} sample positions of the atoms, got shape {np.shape(x)}")
         xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
         with torch.cuda.device(dev):
             _lib.check(
@@ -462,7 +482,35 @@ def finish(result_tensor, was_numpy, was_1d, widen=False):
             _lib.check(_lib.load().qi_widen(t.device.index, _lib.ptr(src), _lib.ptr(wide), src.numel(), _lib.stream_ptr(t.device)))
         t = wide
     if t.numel() * t.element_size() >= (1 << 20):
-        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        host.copy_(t)
-        return host.numpy()
+        return _staged_copy(t)
     return t.cpu().numpy()
+
+
+_STAGE_BYTES = 64 << 20
+_STAGE = []  # two page-locked staging buffers, made once (PyTorch's pinned allocator never unpins what it freed)
+
+
+def _staged_copy(t):
+    """Device tensor -> pageable NumPy array through two fixed page-locked buffers: the device-to-host copy of piece k + 1
+    runs while piece k is copied out of its staging buffer, and no page-locked memory grows with the result (an order-12
+    panel is 1.6 GB and more once widened)."""
+    if not _STAGE:
+        _STAGE.extend(torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2))
+    flat = t.reshape(-1).view(torch.uint8) if not t.is_complex() else torch.view_as_real(t).reshape(-1).view(torch.uint8)
+    out = np.empty(t.shape, dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+    dst = torch.from_numpy(out.reshape(-1).view(np.uint8))
+    total = flat.numel()
+    stream = torch.cuda.current_stream(t.device)
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    pieces = [(o, min(_STAGE_BYTES, total - o)) for o in range(0, total, _STAGE_BYTES)]
+    for k, (o, m) in enumerate(pieces):
+        _STAGE[k & 1][:m].copy_(flat[o : o + m], non_blocking=True)
+        events[k & 1].record(stream)
+        if k:
+            po, pm = pieces[k - 1]
+            events[(k - 1) & 1].synchronize()
+            dst[po : po + pm].copy_(_STAGE[(k - 1) & 1][:pm])
+    po, pm = pieces[-1]
+    events[(len(pieces) - 1) & 1].synchronize()
+    dst[po : po + pm].copy_(_STAGE[(len(pieces) - 1) & 1][:pm])
+    return out

@@ -113,8 +113,10 @@ class StreamPipeline:
     def __init__(self, plan: engine.TfrPlan, host_records, hop: int, block: int = 16, transforms=("cwt", "stx"),
                  power_scale: float = 1.0, keep_time: bool = True):
         self.plan, self.hop, self.block = plan, int(hop), int(block)
-        self.sig = host_records if isinstance(host_records, np.ndarray) else np.asarray(host_records)
-        if self.sig.ndim == 1:
+        # an ndarray / memmap, or any object with a 2-D `shape` that answers [channel slice, sample slice] with an array
+        # (a rank of the 24 h job materialises only the records it owns)
+        self.sig = host_records if hasattr(host_records, "shape") and hasattr(host_records, "__getitem__") else np.asarray(host_records)
+        if len(self.sig.shape) == 1:
             self.sig = self.sig[None, :]
         self.transforms = tuple(transforms)
         for t in self.transforms:
@@ -123,19 +125,27 @@ class StreamPipeline:
         self.power_scale, self.keep_time = power_scale, keep_time
         self.items = work_items(self.sig.shape[0], self.block, self.sig.shape[1], plan.n, self.hop)
         np_dtype = np.float64 if plan.rdtype == torch.float64 else np.float32
-        self._pinned = [torch.empty((self.block, plan.n), dtype=plan.rdtype).pin_memory() for _ in range(2)]
+        # (a plan on the CPU exists only as the stand-in of bench.py --stub: the item walk without streams or pinning)
+        self._gpu = torch.device(plan.device).type == "cuda"
+        self._pinned = [torch.empty((self.block, plan.n), dtype=plan.rdtype) for _ in range(2)]
+        if self._gpu:
+            self._pinned = [p.pin_memory() for p in self._pinned]
         self._pinned_np = [p.numpy() for p in self._pinned]
         assert self._pinned_np[0].dtype == np_dtype
         self._dev = [torch.empty((self.block, plan.n), dtype=plan.rdtype, device=plan.device) for _ in range(2)]
-        self._copy_stream = torch.cuda.Stream(device=plan.device)
-        self._copied = [torch.cuda.Event() for _ in range(2)]    # H2D of buffer j done
-        self._consumed = [torch.cuda.Event() for _ in range(2)]  # transforms that read buffer j done
+        self._copy_stream = torch.cuda.Stream(device=plan.device) if self._gpu else None
+        self._copied = [torch.cuda.Event() for _ in range(2)] if self._gpu else None    # H2D of buffer j done
+        self._consumed = [torch.cuda.Event() for _ in range(2)] if self._gpu else None  # transforms that read buffer j done
         self._used = [False, False]
         self._out = {}  # (transform, channels) -> result buffers reused item after item
 
     def _stage(self, j, item):
         """Host gather of one item into pinned buffer j and its asynchronous copy to device buffer j."""
         c0, cb, _, s = item
+        if not self._gpu:
+            np.copyto(self._pinned_np[j][:cb], self.sig[c0 : c0 + cb, s : s + self.plan.n], casting="same_kind")
+            self._dev[j][:cb].copy_(self._pinned[j][:cb])
+            return
         if self._used[j]:
             self._copied[j].synchronize()  # the previous copy out of this pinned buffer has finished
         np.copyto(self._pinned_np[j][:cb], self.sig[c0 : c0 + cb, s : s + self.plan.n], casting="same_kind")
@@ -150,14 +160,15 @@ class StreamPipeline:
         mine = rank_items(self.items, rank, world)[first_item:]
         if not mine:
             return
-        compute = torch.cuda.current_stream(self.plan.device)
+        compute = torch.cuda.current_stream(self.plan.device) if self._gpu else None
         self._stage(0, mine[0])
         for k, item in enumerate(mine):
             j = k & 1
             if k + 1 < len(mine):
                 self._stage(j ^ 1, mine[k + 1])  # next item's gather + copy overlap this item's transforms
             c0, cb, chunk, s = item
-            compute.wait_event(self._copied[j])
+            if self._gpu:
+                compute.wait_event(self._copied[j])
             x = self._dev[j][:cb]
             res = {}
             if self.transforms == ("cwt", "stx"):
@@ -171,7 +182,8 @@ class StreamPipeline:
                     fn = self.plan.cwt if t == "cwt" else self.plan.stx
                     self._out[key] = fn(x, coef=False, reductions=True, power_scale=self.power_scale, out=self._out.get(key))
                     res[t] = self._out[key]
-            self._consumed[j].record(compute)
+            if self._gpu:
+                self._consumed[j].record(compute)
             kept = {t: self._keep(r) for t, r in res.items()}
             yield StreamItem(first_item + k, c0, cb, chunk, s, kept.get("cwt"), kept.get("stx"))
 

@@ -111,8 +111,7 @@ def scale_log2_64(in_array):
 def _scaled_bits(p):
     """log2(P + eps) - max(log2(P + eps)) per channel; log2 is monotonic so the max is taken on P."""
     _, _, stats = power_marginals(p)
-    ref = torch.log2(stats[:, 0] + _EPS).contiguous()
-    return _log2_offset(p, ref)
+    return _log2_offset(p, _log2_offset(stats[:, 0:1].contiguous())[:, 0].contiguous())
 
 
 def scale_power_bits(power):
@@ -125,7 +124,7 @@ def power_dynamics_scaled_bits(tfr_power):
     """(power bits re max [B x n], per-time bits [n], per-frequency bits [B]) (ref tfr_info.py:82-94)."""
     p, was_numpy, nd = _as_panel(tfr_power)
     band, time, stats = power_marginals(p)
-    bits = _log2_offset(p, torch.log2(stats[:, 0] + _EPS).contiguous())
+    bits = _log2_offset(p, _log2_offset(stats[:, 0:1].contiguous())[:, 0].contiguous())
     per_time = _scaled_bits(time.unsqueeze(1))[:, 0]
     per_freq = _scaled_bits(band.to(p.dtype).unsqueeze(1))[:, 0]
     squeeze = (lambda t: t[0]) if nd <= 2 else (lambda t: t)

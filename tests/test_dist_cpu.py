@@ -161,3 +161,59 @@ def test_bench_rank_plumbing_world2(tmp_path):
                 assert torch.all(band == 1000.0 * rank + 100.0 * k + call) and torch.all(stats == call)
                 assert torch.all(time == float(rank + k))
     assert seen == {calls - 2, calls - 1}
+
+
+def _torchrun(args, timeout=600):
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", *args]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_default_multirank_run_is_configs3_world2():
+    """`bench.py --gpus N` with no --config (what the driver's scaling run launches): `value` is BASELINE configs[3] -- 64
+    records per GPU, order 12, the STFT in the step, one gather of the reduced product -- and the one-record-per-GPU case
+    rides along under its own key.  Stub transforms, short records (2^12), two gloo ranks."""
+    line = _torchrun(["--steps", "2", "--warmup", "1", "--stub", "1", "--log2n", "12", "--settle-ms", "0"])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["world_size"] == 2 and cfg["backend"].startswith("gloo")
+    assert cfg["channels_per_gpu"] == 64 and "configs[3]" in cfg["workload"] and "128 channels" in cfg["workload"]
+    assert cfg["points_per_step"] == 2 * 128 * cfg["bands"] * 4096
+    assert len(cfg["rank_seconds"]) == 2 and len(cfg["gather_wait_ms_per_step"]) == 2
+    assert cfg["gather_message_bytes_per_rank"] > 0
+    nested = line["configs1_per_gpu"]
+    assert nested["config"]["channels_per_gpu"] == 1 and nested["n_gpus"] == 2 and nested["steps"] == 2
+    assert "scaling_note" in line
+
+
+def test_bench_stream_items_sharded_world2(tmp_path):
+    """`bench.py --config 4 --stub 1` on two gloo ranks: the (channel block, chunk) items of the record set are dealt by
+    stream.rank_items -- every item exactly once, a rank touches only records it owns (OwnedRecords raises otherwise),
+    the JSON line counts both ranks' items."""
+    from quantum_inferno_amd import stream
+
+    dump = os.path.join(str(tmp_path), "stream")
+    line = _torchrun(["--config", "4", "--stub", "1", "--log2n", "12", "--channels", "2", "--stream-chunks", "7", "--warmup", "2",
+                      "--stub-dump", dump])
+    n, hop, chunks, block = 4096, 2048, 7, 2
+    total = n + (chunks - 1) * hop
+    items = stream.work_items(2 * block, block, total, n, hop)
+    assert len(items) == 2 * chunks
+    seen = []
+    for rank in range(2):
+        got = torch.load(f"{dump}.rank{rank}")
+        mine = [tuple(i) for i in got["items"]]
+        assert mine == [tuple(i) for i in stream.rank_items(items, rank, 2)]
+        assert all(c0 == rank * block for c0, _, _, _ in mine)  # a rank's share is its own block of records
+        assert got["timed"] == [(c0, ch) for c0, _, ch, _ in mine[got["warm"]:]]
+        seen += mine
+    assert sorted(seen) == sorted(tuple(i) for i in items)
+    assert line["config"]["rank_items"] == [chunks - 2, chunks - 2] and line["steps"] == chunks - 2
+    assert line["config"]["world_size"] == 2 and line["n_gpus"] == 2
+    assert line["config"]["points_per_step"] == 2 * block * line["config"]["bands"] * n * 2
