@@ -383,6 +383,14 @@ struct qi_plan {
   int native_fuse = 4;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
                                // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
+#ifdef QI_BLK_LZ
+  int native_blk_lz = 3;
+#else
+  int native_blk_lz = 0;
+#endif
+  // ^ local zoom, an experiment that needs a -DQI_BLK_LZ build (bit 0: the 512-sample reach group, bit 1: the 1024-sample group): block bands of the 512- / 1024-sample reach groups with <= 256 / 128 - 16 spectrum bins from coarse samples + interpolation (qi_block.hip, lz_bands)
+  float* d_lz_w = nullptr;     // [2][8][kBlkLzTaps] interpolation weights of the local zoom
+  int native_blk_fastw = 1;    // Gaussian weights without wrap-around logic where no alias of the filter spectrum matters
   int native_blk_long = 1;     // narrow Gaussian bands of the 1024-sample reach group in 8192-sample blocks (75 % of the outputs kept instead of 50 %)
   int native_blk_half = 1;     // block bands whose filter spectrum lies in the lower half of the block spectrum: eight weights, pruned first pass
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch
@@ -831,14 +839,35 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   bt.demod = demod;
   // reach groups: taps within 256, 512, 1024 samples (4096-sample blocks), and the long blocks (8192 samples) for the
   // narrow Gaussian bands of the 1024-sample group whose spectrum lies in the lower half of the 8192-bin grid
-  constexpr int NG = 4;
-  const int wqs[NG] = {1, 2, 4, native::kBlkLongWq};
+  // ... and the local zoom items (narrow Gaussian bands of the 512- and 1024-sample groups at the decimated rate)
+  constexpr int NG = 6;
+  const int wqs[NG] = {1, 2, 4, native::kBlkLongWq, native::kBlkLzA, native::kBlkLzB};
+  // local zoom: the weights above 2^-30 of the peak within 4096 / (8 D) bins of the baseband centre (the band is then
+  // oversampled >= 4 times on the coarse grid); the centre is the band's own for a Stockwell band and the next multiple of
+  // 16 bins for a Gabor band (<= 8 bins off)
+  auto lz_kind = [&](const BlockPick& pk) -> int {
+    if (!p->native_blk_lz || !p->native_blk_analytic || !p->native_blk_narrow || !pk.analytic) return 0;
+    const double half = std::ceil(std::sqrt(30.0) / pk.cw);
+    if (2.0 * half + 2.0 > 256.0) return 0;
+    const double margin = demod ? 2.0 : 10.0;
+    if ((p->native_blk_lz & 1) && pk.wq == 2 && half + margin <= 128.0) return native::kBlkLzA;
+    if ((p->native_blk_lz & 2) && pk.wq == 4 && half + margin <= 64.0) return native::kBlkLzB;
+    return 0;
+  };
+  if (p->native_blk_lz && !p->d_lz_w) {
+    std::vector<float> wts(2 * 8 * native::kBlkLzTaps, 0.0f);
+    native::lz_weights(2, wts.data());
+    native::lz_weights(3, wts.data() + 8 * native::kBlkLzTaps);
+    QI_HIP(hipMalloc((void**)&p->d_lz_w, wts.size() * sizeof(float)));
+    QI_HIP(hipMemcpy(p->d_lz_w, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   // first bin of the 256-bin window of a long band: centred on the band, kept inside the lower half of the 8192-bin grid
   // (the half a long block holds)
   auto long_window = [&](const BlockPick& pk) {
     return std::min<int64_t>(std::max<int64_t>((int64_t)std::llround(2.0 * pk.kappa) - 128, 0), native::kBlk - 256);
   };
   auto long_ok = [&](const BlockPick& pk, int cut) {
+    if (lz_kind(pk)) return false;
     if (cut == 0) return false;  // few records: the long blocks' own launch would cost more than the blocks save
     if (!p->native_blk_long || !p->native_blk_analytic || !p->native_blk_narrow || pk.wq != 4 || !pk.analytic) return false;
     if (p->n < 4 * native::kBlkLong) return false;
@@ -861,7 +890,9 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       const int32_t first = (int32_t)list.size();
       for (int32_t r = 0; r < rows; ++r) {
         const bool is_long = long_ok(picks[r], v);
-        if (g == 3 ? !is_long : (picks[r].wq != wqs[g] || is_long)) continue;
+        const int lz = lz_kind(picks[r]);
+        const int home = lz ? lz : (is_long ? native::kBlkLongWq : picks[r].wq);  // the group that takes this band
+        if (home != wqs[g]) continue;
         native::BlockBand b;
         memset(&b, 0, sizeof(b));
         b.out_band = picks[r].band;
@@ -892,6 +923,20 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
         } else if (b.analytic && p->native_blk_half && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)(native::kBlk / 2)) {
           b.narrow = 2;  // every weight above 2^-30 of the peak lies in the lower half of the block spectrum
         }
+        if (b.analytic && p->native_blk_fastw && b.amp > 0.0f && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)native::kBlk) {
+          b.nowrap = 1;
+          b.la = (float)std::log2(picks[r].amp / grid);
+        }
+        if (lz) {
+          if (b.narrow != 1) {
+            set_error("block engine: a local-zoom band without a 256-bin window");
+            return QI_ERR_STATE;
+          }
+          b.narrow = 3;
+          b.kc = (int32_t)(((16 * (int64_t)std::llround(kappa / 16.0)) % native::kBlk + native::kBlk) % native::kBlk);
+          b.rot_lz[0] = (float)std::cos(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
+          b.rot_lz[1] = (float)std::sin(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
+        }
         for (int k = 0; k < 4; ++k) {
           // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
           const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
@@ -913,17 +958,19 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       if (nblocks > bt.max_blocks) bt.max_blocks = nblocks;
       for (int32_t q = first; q < (int32_t)list.size(); ++q) il.h_bands.push_back({list[q].out_band, (int32_t)nblocks});
     }
-    const int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
     std::vector<native::BlockItem> items;
     for (int g = 0; g < NG; ++g) {
       const int32_t first = group_first[g], count = group_count[g];
       if (count == 0) continue;
-      // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
+      // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block); a
+      // local-zoom workgroup takes its bands D at a time (one run of the LDS passes per D bands)
+      int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
+      if (const int l2d = native::lz_log2d(wqs[g])) per_wg = v == 0 ? (1 << l2d) : (l2d == 2 ? 12 : 8);
       const int32_t nchunk = (int32_t)ceil_div(count, per_wg);
       const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
       if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d%s: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
-                g == 3 ? 1024 : 256 * wqs[g], g == 3 ? " (8192-sample blocks)" : "", count,
+                g == 3 ? 1024 : 256 * (wqs[g] & 15), g == 3 ? " (8192-sample blocks)" : (g > 3 ? " (local zoom)" : ""), count,
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.analytic != 0; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 1; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 2; }),
@@ -1601,6 +1648,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.items = il.d_items;
       b.bands = il.d_bands;
       b.bank = static_cast<const cplx<T>*>(bt.bank);
+      b.lz_w = p->d_lz_w;
       b.sig = sig + c0 * n;
       b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
       b.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
@@ -2326,6 +2374,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_LONG")) p->native_blk_long = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK_FASTW")) p->native_blk_fastw = atoi(e);
+#ifdef QI_BLK_LZ
+  if (const char* e = tune_env("QI_NATIVE_BLK_LZ")) p->native_blk_lz = atoi(e);
+#endif
   if (const char* e = tune_env("QI_NATIVE_ROWS")) {
     const long v = atol(e);
     if (v == 8 || v == 16) p->native_rows = (int)v;
@@ -2412,6 +2464,7 @@ int qi_plan_destroy(qi_plan* p) {
       if (w) (void)hipFree(w);
   if (p->d_edge) (void)hipFree(p->d_edge);
   if (p->split_bank) (void)hipFree(p->split_bank);
+  if (p->d_lz_w) (void)hipFree(p->d_lz_w);
   if (p->d_split_bands) (void)hipFree(p->d_split_bands);
   for (auto* d : p->d_dual)
     if (d) (void)hipFree(d);

@@ -351,6 +351,39 @@ int launch_zoom2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, in
 // weights, solved in long double.  Worst-case error of a unit tone anywhere in the band, float32 weights included:
 // 9e-8 (N = 10, r = 4), 6e-7 (N = 6, r = 8), 3e-7 (N = 4, r = 32); the 12-tap Kaiser-windowed sinc it replaces: 6e-7.
 // Layout [tap][lane].
+// N taps (nodes -N/2 + 1 .. N/2) of the interpolator to the fraction x in [0, 1) that is exact at the Chebyshev nodes of
+// the band [-band, band] (radians per coarse sample); out[c] belongs to node c - N/2 + 1
+static void interp_taps(int N, long double band, long double x, long double* out) {
+  const int half = N / 2;
+  long double M[10][11];
+  for (int k = 0; k < half; ++k) {
+    const long double om = band * std::cos((long double)(2 * k + 1) * 3.14159265358979323846264338327950288L / (long double)(2 * N));
+    for (int c = 0; c < N; ++c) {
+      const long double node = (long double)(c - half + 1);
+      M[k][c] = std::cos(om * node);
+      M[half + k][c] = std::sin(om * node);
+    }
+    M[k][N] = std::cos(om * x);
+    M[half + k][N] = std::sin(om * x);
+  }
+  for (int c = 0; c < N; ++c) {  // Gauss-Jordan with partial pivoting
+    int piv = c;
+    for (int r = c + 1; r < N; ++r)
+      if (std::fabs((double)M[r][c]) > std::fabs((double)M[piv][c])) piv = r;
+    if (piv != c)
+      for (int k = 0; k <= N; ++k) std::swap(M[c][k], M[piv][k]);
+    const long double d = M[c][c];
+    for (int k = 0; k <= N; ++k) M[c][k] /= d;
+    for (int r = 0; r < N; ++r) {
+      if (r == c) continue;
+      const long double f = M[r][c];
+      if (f != 0.0L)
+        for (int k = 0; k <= N; ++k) M[r][k] -= f * M[c][k];
+    }
+  }
+  for (int c = 0; c < N; ++c) out[c] = M[c][N];
+}
+
 void zoom_weights(int cls, int lane_off, float* w) {
   const int taps = zoom_taps(cls), N = zoom_ntap(cls), half = N / 2;
   const long double D = (long double)(kZoomD >> zoom_grid(cls));
@@ -359,38 +392,25 @@ void zoom_weights(int cls, int lane_off, float* w) {
     const long double pos = (long double)(lane - lane_off) / D;
     const int q = (int)std::floor((double)pos);
     const long double x = pos - (long double)q;
-    // nodes o = -half + 1 .. half; equations: cos and sin rows at the half positive Chebyshev nodes
-    long double M[10][11];
-    for (int k = 0; k < half; ++k) {
-      const long double om = band * std::cos((long double)(2 * k + 1) * 3.14159265358979323846264338327950288L / (long double)(2 * N));
-      for (int c = 0; c < N; ++c) {
-        const long double node = (long double)(c - half + 1);
-        M[k][c] = std::cos(om * node);
-        M[half + k][c] = std::sin(om * node);
-      }
-      M[k][N] = std::cos(om * x);
-      M[half + k][N] = std::sin(om * x);
-    }
-    for (int c = 0; c < N; ++c) {  // Gauss-Jordan with partial pivoting
-      int piv = c;
-      for (int r = c + 1; r < N; ++r)
-        if (std::fabs((double)M[r][c]) > std::fabs((double)M[piv][c])) piv = r;
-      if (piv != c)
-        for (int k = 0; k <= N; ++k) std::swap(M[c][k], M[piv][k]);
-      const long double d = M[c][c];
-      for (int k = 0; k <= N; ++k) M[c][k] /= d;
-      for (int r = 0; r < N; ++r) {
-        if (r == c) continue;
-        const long double f = M[r][c];
-        if (f != 0.0L)
-          for (int k = 0; k <= N; ++k) M[r][k] -= f * M[c][k];
-      }
-    }
+    long double t[10];
+    interp_taps(N, band, x, t);
     for (int j = 0; j < taps; ++j) w[j * kWave + lane] = 0.0f;
     for (int c = 0; c < N; ++c) {
       const int j = (half - 1) + q + (c - half + 1);
-      if (j >= 0 && j < taps) w[j * kWave + lane] = (float)M[c][N];
+      if (j >= 0 && j < taps) w[j * kWave + lane] = (float)t[c];
     }
+  }
+}
+
+// Local zoom of the block engine (qi_block.hip): 10 taps per output phase p = 0 .. D - 1 (x = p / D), bands oversampled
+// >= 4 times on their coarse grid; w[p][c] multiplies coarse sample q - 4 + c, q = floor(u / D)
+void lz_weights(int log2d, float* w) {
+  const int D = 1 << log2d;
+  const long double band = 3.14159265358979323846264338327950288L / 4.0L;
+  for (int p = 0; p < D; ++p) {
+    long double t[10];
+    interp_taps(kBlkLzTaps, band, (long double)p / (long double)D, t);
+    for (int c = 0; c < kBlkLzTaps; ++c) w[p * kBlkLzTaps + c] = (float)t[c];
   }
 }
 

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Print the headline figures of bench.py JSON lines (tools/show_bench.py file.json ...)."""
+import json
+import sys
+
+
+def show(x, ind=0):
+    pad = " " * ind
+    r = x["roofline"]
+    print(f"{pad}{x['config']['workload'][:60]}")
+    print(f"{pad}  value {x['value']:.0f}  ms/step {x['ms_per_step']}  step_frac {x['step_roofline']['frac']}")
+    print(f"{pad}  dominant {r['kernel']} frac {r['frac']} launch_ms {r['launch_ms']}")
+    for k, v in x.get("stage_rooflines", {}).items():
+        print(f"{pad}  stage {k} frac {v['frac']} launch_ms {v['launch_ms']} x{v['launches_per_step']}")
+    print(f"{pad}  stages {x['step_roofline']['stage_ms_per_step']}")
+    if "stft" in x:
+        print(f"{pad}  stft {x['stft']['ms_per_step']} ms frac {x['stft']['frac']}")
+    if "two_streams" in x:
+        print(f"{pad}  two_streams {x['two_streams']['value']}")
+
+
+for f in sys.argv[1:]:
+    for ln in open(f):
+        if not ln.startswith("{"):
+            continue
+        d = json.loads(ln)
+        print("==", f)
+        show(d)
+        for k in ("configs2", "f64", "configs1_per_gpu"):
+            if k in d:
+                print(" ", k)
+                show(d[k], 4)
