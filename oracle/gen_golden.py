@@ -312,28 +312,39 @@ def gen_corners():
     save("corners_n2048.npz", **d)
 
 
-def gen_sized(log2n, orders, fs, name, all_rows=False):
+def gen_sized(log2n, orders, fs, name, all_rows=False, dtype=np.float32, channel=(0, 1), transforms=("cwt", "stx", "chirp")):
     """all_rows: keep EVERY band (at the sampled times) instead of three, so that each sub-engine of the native path
-    (zoom levels, block reach groups, narrow / wide filter spectra, split bands) is pinned by the reference."""
+    (zoom levels, block reach groups, narrow / wide filter spectra, split bands) is pinned by the reference.
+    dtype: of the record handed to the reference (float64: the reference then works in double throughout);
+    channel = (c, of): record c of a batch of `of` (the phase offset and noise seed of that channel);
+    transforms: which of the three panels to capture."""
     d = {}
     n = 2 ** log2n
-    sig = synth_chirp(n, fs, dtype=np.float32)
+    sig = synth_chirp(n, fs, channel[0], channel[1], dtype=dtype)
     if n <= 65536:
         d["sig"] = sig
     else:  # regenerated by the tests with the same seeded generator; pinned by samples
         d["sig_samples"] = sig[:: n // 4096]
     for order in orders:
-        f, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
+        f = scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
         rows = np.arange(len(f)) if all_rows else np.array([0, len(f) // 2, len(f) - 1])
         d[f"f_o{order}"], d[f"rows_o{order}"] = f, rows
-        for k, v in panel_digest(cwt, rows, all_rows).items():
-            d[f"cwt_{k}_o{order}"] = v
-        del cwt
-        print(f"  n=2^{log2n} order {order} cwt done", flush=True)
-        f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
-        for k, v in panel_digest(stx, rows, all_rows).items():
-            d[f"stx_{k}_o{order}"] = v
-        del stx
+        if "cwt" in transforms:
+            f1, t, cwt = styx_cwt.cwt_complex_any_scale_pow2(order, sig, fs)
+            assert np.array_equal(f1, f)
+            for k, v in panel_digest(cwt, rows, all_rows).items():
+                d[f"cwt_{k}_o{order}"] = v
+            del cwt
+            print(f"  n=2^{log2n} order {order} cwt done", flush=True)
+        if "stx" in transforms:
+            f2, t2, stx = styx_stx.stx_complex_any_scale_pow2(order, sig, fs)
+            assert np.array_equal(f2, f)
+            for k, v in panel_digest(stx, rows, all_rows).items():
+                d[f"stx_{k}_o{order}"] = v
+            del stx
+        if "chirp" not in transforms:
+            print(f"  n=2^{log2n} order {order} done", flush=True)
+            continue
         c, bits, tc, fc = quiet(cwt_atoms.cwt_chirp_from_sig, sig, fs, order)
         rows_c = np.arange(len(fc)) if all_rows else np.array([0, len(fc) // 2, len(fc) - 1])
         d[f"chirp_f_o{order}"], d[f"chirp_rowsel_o{order}"] = fc, rows_c
@@ -373,5 +384,11 @@ if __name__ == "__main__":
         gen_sized(16, (3, 12), 800.0, "large_n65536.npz")
     if "large" in todo or "large20" in todo:
         gen_sized(20, (3,), 1000.0, "large_n1048576.npz", all_rows=True)
+    if "large20f64" in todo:  # the same record in float64: the reference works in double throughout (~10 GB RSS)
+        gen_sized(20, (3,), 1000.0, "large_n1048576_f64.npz", all_rows=True, dtype=np.float64, transforms=("cwt", "stx"))
+    if "cfg3ch63" in todo:  # channel 63 of the BASELINE configs[2] batch, Stockwell only (~3 GB RSS)
+        gen_sized(20, (12,), 1000.0, "large_n1048576_o12_ch63_stx.npz", all_rows=True, channel=(63, 64), transforms=("stx",))
+    if "o6n19" in todo:  # an order-6 table at 2^19 samples: other zoom classes / reach groups than orders 3 and 12 at 2^20
+        gen_sized(19, (6,), 1000.0, "large_n524288_o6.npz", all_rows=True, transforms=("cwt", "stx"))
     if "large12" in todo:  # BASELINE configs[2] per channel: order 12 (167 bands) at 2^20 samples; ~30 GB RSS, ~6 min
         gen_sized(20, (12,), 1000.0, "large_n1048576_o12.npz", all_rows=True)

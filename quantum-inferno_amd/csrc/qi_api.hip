@@ -320,7 +320,7 @@ struct qi_plan {
     // for calls with one or two records --, [1] many bands per workgroup -- fewer forward transforms of the same block
     // and fewer per-time planes, for batches that fill the chip anyway.
     struct ItemList {
-      native::BlockBand* d_bands = nullptr;  // all reach groups, group by group (cut 1 keeps some bands on long blocks)
+      void* d_bands = nullptr;  // native::BlockBandT<T>[]: all reach groups, group by group (cut 1 keeps some bands on long blocks)
       std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
       native::BlockItem* d_items = nullptr;
       int32_t nitems = 0, nplanes = 0;
@@ -845,7 +845,11 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   // local zoom: the weights above 2^-30 of the peak within 4096 / (8 D) bins of the baseband centre (the band is then
   // oversampled >= 4 times on the coarse grid); the centre is the band's own for a Stockwell band and the next multiple of
   // 16 bins for a Gabor band (<= 8 bins off)
+  // (float64 tables: Gaussian weights in double from every bin -- the shortcuts below drop weights under 2^-30 of the peak)
+  constexpr bool F64 = sizeof(T) == 8;
+  const double drop_bits = F64 ? 52.0 : 30.0;
   auto lz_kind = [&](const BlockPick& pk) -> int {
+    if (F64) return 0;
     if (!p->native_blk_lz || !p->native_blk_analytic || !p->native_blk_narrow || !pk.analytic) return 0;
     const double half = std::ceil(std::sqrt(30.0) / pk.cw);
     if (2.0 * half + 2.0 > 256.0) return 0;
@@ -867,7 +871,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     return std::min<int64_t>(std::max<int64_t>((int64_t)std::llround(2.0 * pk.kappa) - 128, 0), native::kBlk - 256);
   };
   auto long_ok = [&](const BlockPick& pk, int cut) {
-    if (lz_kind(pk)) return false;
+    if (F64 || lz_kind(pk)) return false;
     if (cut == 0) return false;  // few records: the long blocks' own launch would cost more than the blocks save
     if (!p->native_blk_long || !p->native_blk_analytic || !p->native_blk_narrow || pk.wq != 4 || !pk.analytic) return false;
     if (p->n < 4 * native::kBlkLong) return false;
@@ -884,7 +888,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   }
   for (int v = 0; v < 2; ++v) {
     auto& il = bt.var[v];
-    std::vector<native::BlockBand> list;
+    std::vector<native::BlockBandT<T>> list;
     int32_t group_first[NG] = {0, 0, 0, 0}, group_count[NG] = {0, 0, 0, 0};
     for (int g = 0; g < NG; ++g) {
       const int32_t first = (int32_t)list.size();
@@ -893,7 +897,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
         const int lz = lz_kind(picks[r]);
         const int home = lz ? lz : (is_long ? native::kBlkLongWq : picks[r].wq);  // the group that takes this band
         if (home != wqs[g]) continue;
-        native::BlockBand b;
+        native::BlockBandT<T> b;
         memset(&b, 0, sizeof(b));
         b.out_band = picks[r].band;
         b.bank_row = r;
@@ -902,30 +906,34 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
         const double grid = is_long ? 2.0 : 1.0;  // the band on the 8192-bin grid of a long block: twice the bins
         const double kappa = grid * picks[r].kappa, cw = picks[r].cw / grid;
         b.kappa_int = (int32_t)std::floor(kappa);
-        b.kappa_frac = (float)(kappa - std::floor(kappa));
-        b.cw = (float)cw;
-        b.amp = (float)(picks[r].amp / grid);
-        // weights >= 2^-30 of the peak: |cw dk| <= sqrt(30)
-        const double half = std::ceil(std::sqrt(30.0) / cw);
-        if (b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
+        b.kappa_frac = (T)(kappa - std::floor(kappa));
+        b.cw = (T)cw;
+        b.amp = (T)(picks[r].amp / grid);
+        // weights >= 2^-30 of the peak: |cw dk| <= sqrt(30) (float64: 2^-52)
+        const double half = std::ceil(std::sqrt(drop_bits) / cw);
+        if (F64 && !b.analytic) {
+          set_error("block engine: float64 tables take analytic (Gaussian) bands only");
+          return QI_ERR_STATE;
+        }
+        if (!F64 && b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
           b.narrow = 1;
           b.klo = is_long ? (int32_t)long_window(picks[r])
                           : (int32_t)((((int64_t)std::llround(kappa) - 128) % native::kBlk + native::kBlk) % native::kBlk);
           const int ba = b.klo >> 8;
-          b.rot_a[0] = (float)std::cos(2.0 * M_PI * ba / 16.0);
-          b.rot_a[1] = (float)std::sin(2.0 * M_PI * ba / 16.0);
-          b.rot_b[0] = (float)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
-          b.rot_b[1] = (float)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
-          b.rot8_a[0] = (float)std::cos(M_PI * ba / 16.0);  // exp(2 pi i 256 b / 8192)
-          b.rot8_a[1] = (float)std::sin(M_PI * ba / 16.0);
-          b.rot8_b[0] = (float)std::cos(M_PI * (ba + 1) / 16.0);
-          b.rot8_b[1] = (float)std::sin(M_PI * (ba + 1) / 16.0);
-        } else if (b.analytic && p->native_blk_half && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)(native::kBlk / 2)) {
+          b.rot_a[0] = (T)std::cos(2.0 * M_PI * ba / 16.0);
+          b.rot_a[1] = (T)std::sin(2.0 * M_PI * ba / 16.0);
+          b.rot_b[0] = (T)std::cos(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+          b.rot_b[1] = (T)std::sin(2.0 * M_PI * ((ba + 1) & 15) / 16.0);
+          b.rot8_a[0] = (T)std::cos(M_PI * ba / 16.0);  // exp(2 pi i 256 b / 8192)
+          b.rot8_a[1] = (T)std::sin(M_PI * ba / 16.0);
+          b.rot8_b[0] = (T)std::cos(M_PI * (ba + 1) / 16.0);
+          b.rot8_b[1] = (T)std::sin(M_PI * (ba + 1) / 16.0);
+        } else if (!F64 && b.analytic && p->native_blk_half && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)(native::kBlk / 2)) {
           b.narrow = 2;  // every weight above 2^-30 of the peak lies in the lower half of the block spectrum
         }
-        if (b.analytic && p->native_blk_fastw && b.amp > 0.0f && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)native::kBlk) {
+        if (b.analytic && p->native_blk_fastw && b.amp > (T)0 && kappa - half - 1.0 >= 0.0 && kappa + half + 1.0 < (double)native::kBlk) {
           b.nowrap = 1;
-          b.la = (float)std::log2(picks[r].amp / grid);
+          b.la = (T)std::log2(picks[r].amp / grid);
         }
         if (lz) {
           if (b.narrow != 1) {
@@ -934,20 +942,20 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
           }
           b.narrow = 3;
           b.kc = (int32_t)(((16 * (int64_t)std::llround(kappa / 16.0)) % native::kBlk + native::kBlk) % native::kBlk);
-          b.rot_lz[0] = (float)std::cos(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
-          b.rot_lz[1] = (float)std::sin(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
+          b.rot_lz[0] = (T)std::cos(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
+          b.rot_lz[1] = (T)std::sin(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
         }
         for (int k = 0; k < 4; ++k) {
           // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
           const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
           const double ang = -2.0 * M_PI * (double)m / (double)p->n;
-          b.rot[2 * k] = (float)std::cos(ang);
-          b.rot[2 * k + 1] = (float)std::sin(ang);
+          b.rot[2 * k] = (T)std::cos(ang);
+          b.rot[2 * k + 1] = (T)std::sin(ang);
         }
         {
           const int64_t m1 = picks[r].shift % p->n;  // one sample: the odd sample of a long block's pair
-          b.rot1[0] = (float)std::cos(-2.0 * M_PI * (double)m1 / (double)p->n);
-          b.rot1[1] = (float)std::sin(-2.0 * M_PI * (double)m1 / (double)p->n);
+          b.rot1[0] = (T)std::cos(-2.0 * M_PI * (double)m1 / (double)p->n);
+          b.rot1[1] = (T)std::sin(-2.0 * M_PI * (double)m1 / (double)p->n);
         }
         list.push_back(b);
       }
@@ -971,9 +979,9 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d%s: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
                 g == 3 ? 1024 : 256 * (wqs[g] & 15), g == 3 ? " (8192-sample blocks)" : (g > 3 ? " (local zoom)" : ""), count,
-                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.analytic != 0; }),
-                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 1; }),
-                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBand& b) { return b.narrow == 2; }),
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.analytic != 0; }),
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.narrow == 1; }),
+                (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.narrow == 2; }),
                 nchunk, (long long)nblocks);
       for (int32_t c = 0; c < nchunk; ++c) {
         const int32_t lo = first + (int32_t)((int64_t)count * c / nchunk);
@@ -1010,8 +1018,8 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       il.nedge_items = (int32_t)items.size() - il.nitems;
     }
     il.h_items = items;
-    QI_HIP(hipMalloc((void**)&il.d_bands, list.size() * sizeof(native::BlockBand)));
-    QI_HIP(hipMemcpy(il.d_bands, list.data(), list.size() * sizeof(native::BlockBand), hipMemcpyHostToDevice));
+    QI_HIP(hipMalloc((void**)&il.d_bands, list.size() * sizeof(native::BlockBandT<T>)));
+    QI_HIP(hipMemcpy(il.d_bands, list.data(), list.size() * sizeof(native::BlockBandT<T>), hipMemcpyHostToDevice));
     QI_HIP(hipMalloc((void**)&il.d_items, items.size() * sizeof(native::BlockItem)));
     QI_HIP(hipMemcpy(il.d_items, items.data(), items.size() * sizeof(native::BlockItem), hipMemcpyHostToDevice));
   }
@@ -1172,7 +1180,9 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     const double w = std::ceil(std::sqrt((p->d.dtype == QI_F64 ? 52.0 : 30.0) * M_LN2 / h_par[j])) + 1.0;
     // (a band of the widest reach groups -- half of each 4096-sample block is overlap there -- goes to the zoom
     // engine instead when its spectrum fits one of its grids)
-    if (can_block && block_group_of(w) > 0 &&
+    // (float64: a band the float64 zoom takes -- support within Lf / 16 bins -- stays there)
+    const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L);
+    if (can_block && block_group_of(w) > 0 && !z64_first &&
         !(block_group_of(w) > p->native_blk_maxwq && zoom_class(p, bank, L, len) >= 0)) {
       BlockPick pk{j, block_group_of(w), 0};
       const double p_re = h_par[j], p_im = h_par[B + j], om = h_par[2 * B + j], am = h_par[3 * B + j];
@@ -1183,6 +1193,15 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
         pk.kappa = om * (double)native::kBlk / (2.0 * M_PI);
         pk.cw = (2.0 * M_PI / (double)native::kBlk) * std::sqrt(M_LOG2E / (4.0 * p_re));
         pk.amp = am * std::sqrt(M_PI / p_re) / (double)native::kBlk;
+      }
+      if (p->d.dtype == QI_F64 && !pk.analytic) {  // (the float64 block kernels evaluate Gaussians only)
+        if (can_short && w <= 8192.0 && w < (double)n / 8) {
+          shorts.push_back(j);
+          short_w.push_back((int32_t)w);
+        } else {
+          keep.push_back(j);
+        }
+        continue;
       }
       picks.push_back(pk);
     } else if (can_short && zoom_class(p, bank, L, len) < 0 && !(len > 0 && len <= narrow_limit(p, bank, L)) && w <= 8192.0 &&
@@ -1646,7 +1665,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.edge_part = zadd;
       b.panel_bands = (int32_t)B;
       b.items = il.d_items;
-      b.bands = il.d_bands;
+      b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);
       b.bank = static_cast<const cplx<T>*>(bt.bank);
       b.lz_w = p->d_lz_w;
       b.sig = sig + c0 * n;
@@ -1985,8 +2004,10 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   // partial slots per band: the row groups of the two-pass kernels (the circular sub-table has half as many) or the tiles
   // of the float64 zoom, whichever is more
   const int64_t nblk_z = n / native::kZ64Tile;
-  const int64_t nblk = subs[0].nblk > nblk_z ? subs[0].nblk : nblk_z;
-  const bool clear_parts = shorts || subs[0].nblk != nblk;  // (some bands leave slots unwritten)
+  int64_t nblk = subs[0].nblk > nblk_z ? subs[0].nblk : nblk_z;
+  if (p->blk[kind].ready && kind != 1 && p->blk[kind].max_blocks > nblk) nblk = p->blk[kind].max_blocks;
+  // (some bands leave slots unwritten: the block bands fill one slot per block of their reach group)
+  const bool clear_parts = shorts || subs[0].nblk != nblk || (p->blk[kind].ready && kind != 1);
   // float64 zoom bands: one launch per coarse-grid level, its bands dealt to `zchunk` workgroups per tile
   int zchunk[native::kZ64Levels] = {};
   size_t e_z = 0;  // coarse storage of the largest level (the levels run one after the other)
@@ -1998,6 +2019,19 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     const size_t bytes = (size_t)t.z64_count[g] * (size_t)((Lf / 64) << g) * sizeof(cplx<T>);
     if (bytes > e_z) e_z = bytes;
   }
+  // block engine (short-atom bands with wide spectra, double arithmetic): its planes and stat slots come last
+  const auto& bt = p->blk[kind];
+  const bool blocks = kind != 1 && bt.ready;
+  const auto& il = bt.var[C >= 4 ? 1 : 0];
+  const int chunk_blk = chunk_total;
+  int64_t blk_stats = 0;
+  if (blocks) {
+    chunk_total += il.nplanes;
+    blk_stats = il.nitems;
+  }
+  // stat slots: [chunks of the two-pass and zoom launches][nblk], then one per block item, then the edge bands
+  const int64_t blk_stat_base = (int64_t)chunk_blk * nblk;
+  const int64_t stat_slots = blk_stat_base + blk_stats + (shorts ? p->nedge : 0);
   if (chunk_total == 0) {
     set_error("float64 native table has no band");
     return QI_ERR_STATE;
@@ -2005,7 +2039,6 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr, want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
   const int64_t nbk = nblk + (shorts ? 1 : 0);  // partial slots per band (last one: the corrected edge samples)
-  const int64_t stat_slots = (int64_t)chunk_total * nblk + (shorts ? p->nedge : 0);
   const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
   const size_t e_imd = (size_t)imd_elems * sizeof(cplx<T>);
@@ -2141,6 +2174,32 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       QI_TRY(native::launch_z64_interp(z, zchunk[g], ct, st));
       p->prof.end(QI_STAGE_ZOOM, st);
       chunk_base += zchunk[g];
+    }
+    if (blocks) {
+      native::BlockArgs<T> b{};
+      b.n = n;
+      b.nitems = il.nitems;
+      b.panel_bands = (int32_t)B;
+      b.items = il.d_items;
+      b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);
+      b.bank = static_cast<const cplx<T>*>(bt.bank);
+      b.sig = sig + c0 * n;
+      b.coef = coef;
+      b.bits = bits;
+      b.time_part = tpart;
+      b.part_band = want_band ? part_band : nullptr;
+      b.part_stat = want_stat ? part_stat : nullptr;
+      b.nblk = nbk;
+      b.stat_stride = stat_slots;
+      b.stat_base = blk_stat_base;
+      b.chunk_base = chunk_blk;
+      b.chunk_total = chunk_total;
+      b.power_scale = power_scale;
+      b.eps = eps;
+      b.two_over_n = (float)(2.0 / (double)n);
+      p->prof.begin(st, QI_STAGE_BLOCK);
+      QI_TRY(native::launch_block<T>(b, bt.demod, ct, st));
+      p->prof.end(QI_STAGE_BLOCK, st);
     }
     p->prof.begin(st, QI_STAGE_EPILOGUE);
     if (shorts) {
@@ -2390,7 +2449,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   }
   if (desc->dtype == QI_F64) {  // the float32 zoom / block / split engines are sized for the float32 tolerance
     const int short64 = p->native_short && !(tune_env("QI_NATIVE_SHORT64") && atoi(tune_env("QI_NATIVE_SHORT64")) == 0);
-    p->native_zoom = p->native_block = p->native_split = 0;
+    // (the block engine runs float64 tables in double arithmetic: analytic Gaussian bands, no narrow-spectrum shortcuts)
+    const int block64 = p->native_block && !(tune_env("QI_NATIVE_BLOCK64") && atoi(tune_env("QI_NATIVE_BLOCK64")) == 0);
+    p->native_zoom = p->native_split = 0;
+    p->native_block = block64;
     p->native_short = short64;  // wide-spectrum, short-atom styx bands as circular correlations of length n + edge fix
     p->native_rows = 8;
     if (p->native_group <= 0) p->native_group = 8;  // wide bands per launch group: bounds the intermediate (32 MB per band and record)
@@ -2662,11 +2724,14 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     for (int32_t j = 0; j < B; ++j) {
       // the band's time-domain kernel is a Gaussian of standard deviation sigma_j samples (above 2^-30 of its peak
       // within sqrt(60 ln 2) sigma); it is only that short if the frequency window has decayed before Nyquist
-      const double reach = std::ceil(std::sqrt(60.0 * M_LN2) * sigma[j]) + 1.0;
+      const double reach = std::ceil(std::sqrt((p->d.dtype == QI_F64 ? 104.0 : 60.0) * M_LN2) * sigma[j]) + 1.0;
       const double kh0 = std::floor(std::sqrt(30.0) / coef[j]);
       const bool zoom_first = block_group_of(reach) > p->native_blk_maxwq && 2 * kh0 + 1 < (double)p->n &&
                               zoom_class(p, 2, p->n, (int64_t)(2 * kh0 + 1)) >= 0;
-      if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 && !zoom_first) {
+      const double kh64 = std::floor(cut / coef[j]);
+      const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, 2) && 2 * kh64 + 1 <= (double)narrow_limit(p, 2, p->n) &&
+                             2 * kh64 + 1 < (double)p->n;
+      if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 && !zoom_first && !z64_first) {
         BlockPick pk{j, block_group_of(reach), shift_index[j]};
         // the band's filter spectrum is the Gaussian window itself, centred on the band's shift index
         pk.analytic = 1;
@@ -2699,7 +2764,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
       int rc = upload_native_table(p, 2, p->n, bands);
       if (rc == QI_OK) {
         p->nat[2].nbands = B;
-        rc = build_block_stx<float>(p, picks, coef, nullptr);
+        rc = p->d.dtype == QI_F64 ? build_block_stx<double>(p, picks, coef, nullptr) : build_block_stx<float>(p, picks, coef, nullptr);
       }
       if (rc != QI_OK) {  // no half-built table: a ready table whose block bands have no producer would leave panel rows unwritten
         p->nat[2].release();

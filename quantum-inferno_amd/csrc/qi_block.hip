@@ -73,6 +73,36 @@ __device__ __forceinline__ void half_swap(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ void half_swap(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+// two adjacent complex samples / two adjacent reals of a panel row at sample tt (float: one 16- / 8-byte store)
+__device__ __forceinline__ void store_pair(char* row, uint32_t tt, float2 z0, float2 z1) {
+  stream_store(reinterpret_cast<float4*>(row + (size_t)(tt * (uint32_t)sizeof(float2))), make_float4(z0.x, z0.y, z1.x, z1.y));
+}
+__device__ __forceinline__ void store_pair(char* row, uint32_t tt, double2 z0, double2 z1) {
+  double2* q = reinterpret_cast<double2*>(row + (size_t)tt * sizeof(double2));
+  stream_store(q, z0);
+  stream_store(q + 1, z1);
+}
+__device__ __forceinline__ void store_real_pair(char* row, uint32_t tt, float a, float b) {
+  *reinterpret_cast<float2*>(row + (size_t)(tt * (uint32_t)sizeof(float))) = make_float2(a, b);
+}
+__device__ __forceinline__ void store_real_pair(char* row, uint32_t tt, double a, double b) {
+  *reinterpret_cast<double2*>(row + (size_t)tt * sizeof(double)) = make_double2(a, b);
+}
+// exp(2 pi i x), x formed exactly by the caller (float: x in single precision)
+template <typename T>
+__device__ __forceinline__ cplx<T> unit_phasor(double two_x) {
+  T s, c;
+  sincospi_as<T>(two_x, &s, &c);
+  return mk<T>(c, s);
+}
+
 // S[c] *= r0 * exp(-i pi c / 16), c = 0..15 (the second factor is a compile-time constant: W_64^(-2c))
 template <typename T, int... Cs>
 __device__ __forceinline__ void rotate_rows16(cplx<T> (&S)[16], cplx<T> r0, std::integer_sequence<int, Cs...>) {
@@ -265,9 +295,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
   if (!DEMOD) {
     // Gabor banks: the half-sample offset of the atoms (styx_cwt.py:113-144) is the factor exp(-i theta_k / 2) of
     // every filter spectrum; it goes into the block spectrum once, which leaves REAL Gaussian weights per band
-    float sn, cs;
-    sincospif(-(float)col * (1.0f / (float)kBlk), &sn, &cs);
-    const cplx<T> r0 = mk<T>((T)cs, (T)sn);
+    const cplx<T> r0 = unit_phasor<T>(-(double)col / (double)kBlk);
     rotate_rows16<T>(S, r0, std::make_integer_sequence<int, 16>{});
   }
 
@@ -283,12 +311,13 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
   int pending = -1, par = 0;  // band whose wave sums sit in s_red[par ^ 1] until a barrier has passed
 
   // the band descriptor is fetched one band ahead: its load would otherwise sit in front of the filter loads
-  BlockBand bd_next = a.bands[band_first];
+  BlockBandT<T> bd_next = a.bands[band_first];
   for (int jj = 0; jj < band_count; ++jj) {
-    const BlockBand bd = bd_next;
+    const BlockBandT<T> bd = bd_next;
     if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
     cplx<T> v[16];
-    if (bd.narrow == 1) {
+    constexpr bool F64 = sizeof(T) == 8;  // float64 tables hold analytic bands only, none of them `narrow`
+    if (!F64 && bd.narrow == 1) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
       // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
       QI_BSTAMP(1);
@@ -311,7 +340,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
       sparse_head16<T>(v, mk<T>(x.x * r, x.y * r), om);
       if (!QI_BDBG(4)) fft4096_tail<T, 1>(v, buf, tw256, tid, col);
-    } else if (bd.analytic) {
+    } else if (F64 || bd.analytic) {
       // Gaussian filter spectrum in registers: no table traffic (the table rows cost as much L2 bandwidth as the
       // panel costs HBM bandwidth)
       QI_BSTAMP(1);
@@ -386,7 +415,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    if (bd.narrow != 1 && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    if ((F64 || bd.narrow != 1) && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
     QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;
@@ -398,8 +427,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     if (DEMOD) {
       // exp(-2 pi i idx t / n) at this thread's first output; idx * t mod n is exact in 32-bit wraparound
       const uint32_t m = (0u - (uint32_t)bd.shift * tb0) & (uint32_t)(n - 1);
-      float s, c;
-      sincospif((float)m * a.two_over_n, &s, &c);
+      double s, c;
+      unit_root_t<T>(m, a.two_over_n, &c, &s);
       ph = mk<T>((T)c, (T)s);
     }
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
@@ -450,10 +479,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
           mx = max_t(mx, p);
           pl += plog2p(p);
         }
-        if (COEF && inside && !QI_BDBG(1))
-          stream_store(reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))),
-                       make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
-        if (BITS && inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
+        if (COEF && inside && !QI_BDBG(1)) store_pair(coef_row, tt, z[0], z[1]);
+        if (BITS && inside) store_real_pair(bits_row, tt, lg[0], lg[1]);
       }
     };
     if (t0 + W + V > n) finish_band(std::true_type{});
@@ -482,8 +509,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
   for (int i = 0; i < NOUT; i += 2) {  // (col_p holds the sums of this lane's PAIRS: see finish_band)
     tot += col_p[i] + col_p[i + 1];
     const uint32_t tt = tb_pair + 256u * (uint32_t)i;
-    if (time_row && tt < (uint32_t)n)
-      *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(col_p[i], col_p[i + 1]);
+    if (time_row && tt < (uint32_t)n) store_real_pair(time_row, tt, col_p[i], col_p[i + 1]);
   }
   const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
   __syncthreads();  // the last band's wave sums are visible; buf is free
@@ -1222,6 +1248,37 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   }
 }
 
+// float64 records (run_native64): the same band items in double arithmetic -- Gaussian filter spectra in registers, no
+// narrow-spectrum shortcuts (those drop weights below 2^-30 of the peak), no long blocks, no split bands.  The exchange
+// buffer and the twiddle table take 72 KB of (dynamic) LDS: two workgroups per CU, compiled for two waves per SIMD.
+constexpr size_t kBlk64Lds = (size_t)(kBlkBuf + 256) * sizeof(double2);
+template <bool DEMOD, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem64[];
+  double2* buf = reinterpret_cast<double2*>(smem64);
+  double2* tw256 = buf + kBlkBuf;
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // block_item's column order
+  {
+    double s, c;
+    sincospi((double)tid * (2.0 / 256.0), &s, &c);
+    tw256[tid] = make_double2(c, s);
+  }
+  double2 w;
+  {
+    double s, c;
+    sincospi((double)col * (2.0 / 4096.0), &s, &c);
+    w = make_double2(c, s);
+  }
+  const BlockItem it = a.items[blockIdx.x];
+  switch (it.wq) {
+    case 1: block_item<double, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    case 2: block_item<double, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    default: block_item<double, 4, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+  }
+}
+
 // long-block items (BlockItem::wq = kBlkLongWq) have kernels of their own: their register budget (the even samples of a
 // band are held while its odd samples are transformed) would spill inside k_block / k_block_dual
 template <typename T, bool DEMOD, bool COEF, bool BITS>
@@ -1552,6 +1609,33 @@ int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels
   if (rest.nitems + rest.nedge_items <= 0) return QI_OK;
   dim3 grid((unsigned)(rest.nitems + rest.nedge_items), 1, (unsigned)n_channels);
   return demod ? launch_block_v<float, true>(rest, grid, st) : launch_block_v<float, false>(rest, grid, st);
+}
+
+template <bool DEMOD>
+static int launch_block64_v(const BlockArgs<double>& a, dim3 grid, hipStream_t st) {
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+#define QI_B64(C, B)                                                                                   \
+  do {                                                                                                 \
+    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_block64<DEMOD, C, B>), kBlk64Lds));      \
+    k_block64<DEMOD, C, B><<<grid, kBlkThreads, kBlk64Lds, st>>>(a);                                   \
+  } while (0)
+  if (coef && bits) QI_B64(true, true);
+  else if (coef) QI_B64(true, false);
+  else if (bits) QI_B64(false, true);
+  else QI_B64(false, false);
+#undef QI_B64
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template <>
+int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channels, hipStream_t st) {
+  if (a.nitems <= 0) return QI_OK;
+  if (a.nlong > 0 || a.nedge_items > 0) {
+    set_error("block engine: float64 tables have neither long blocks nor split bands");
+    return QI_ERR_STATE;
+  }
+  dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
+  return demod ? launch_block64_v<true>(a, grid, st) : launch_block64_v<false>(a, grid, st);
 }
 
 template <>

@@ -86,40 +86,44 @@ struct EdgeArgs {
 
 // ---- block engine (qi_block.hip): short-atom bands by overlap-save with 4096-point transforms -------------------
 constexpr int kBlk = 4096;
-struct BlockBand {
+// (R: float for the float32 engine, double for the float64 one -- the block kernels compute in the record's precision)
+template <typename R>
+struct BlockBandT {
   int32_t out_band;  // row of the panel
   int32_t bank_row;  // row of the [rows][kBlk] filter-spectrum table
   int32_t shift;     // Stockwell: shift index idx_j (outputs are multiplied by exp(-2 pi i idx t / n))
   int32_t analytic;  // the filter spectrum is a Gaussian evaluated in registers (no table row is read)
-  float rot[8];      // Stockwell: r^(2^k), k = 0..3, r = exp(-2 pi i idx 256 / n)
+  R rot[8];      // Stockwell: r^(2^k), k = 0..3, r = exp(-2 pi i idx 256 / n)
   // analytic filter: weight(k) = amp * exp2(-(cw * dk)^2), dk = k - (kappa_int + kappa_frac) wrapped to +-kBlk / 2
   int32_t kappa_int;
-  float kappa_frac, cw, amp;
+  R kappa_frac, cw, amp;
   // narrow = 1: the weights above 2^-30 of the peak lie within the 256 bins from `klo` (mod kBlk), so a thread holds at
   // most one non-zero value of the filtered spectrum and the first radix-16 pass of the inverse transform is a
   // product with powers of one phasor; rot_a / rot_b = exp(2 pi i b / 16) for b = klo / 256 and the next one
   // narrow = 2: the weights above 2^-30 of the peak lie within bins (0, kBlk / 2): eight weights per thread and a first
   // pass of the inverse transform without its first radix-2 stage
   int32_t narrow, klo;
-  float rot_a[2], rot_b[2];
+  R rot_a[2], rot_b[2];
   // long blocks (BlockItem::wq = kBlkLongWq: 8192 record samples per block, 6144 outputs kept; narrow Gaussian bands of
   // the 1024-sample reach group): the band on the 8192-bin grid -- kappa_int / kappa_frac / cw / amp / klo / rot_a /
   // rot_b above are then in units of THAT grid --, exp(i pi b / 16) for b = klo / 256 and the next one (the twiddle of the
   // odd output samples), and for the Stockwell demodulation exp(-2 pi i idx / n) (one sample)
-  float rot8_a[2], rot8_b[2];
-  float rot1[2];
+  R rot8_a[2], rot8_b[2];
+  R rot1[2];
   // narrow = 3, local zoom (BlockItem::wq = an lz code): the band's coarse samples -- every D-th output of the inverse
   // transform -- are brought to baseband and the outputs are interpolated from them.  Gabor banks: kc = the baseband centre
   // bin (a multiple of 16 next to kappa: the carrier exp(2 pi i kc u / 4096) of a thread's outputs u = u0 + 256 i does not
   // depend on i), rot_lz = exp(2 pi i kc / 4096) (the odd sample of a pair).  Stockwell bands are demodulated on the coarse
   // grid (shift, rot) and need neither.
   int32_t kc;
-  float rot_lz[2];
+  R rot_lz[2];
   // nowrap = 1: every weight above 2^-30 of the peak belongs to a bin k in [0, kBlk) at distance k - kappa (no alias is
   // nearer), and amp > 0: weight(k) = exp2(la - (cw (k - kappa))^2), la = log2(amp) -- no wrap-around logic per weight
   int32_t nowrap;
-  float la;
+  R la;
 };
+using BlockBand = BlockBandT<float>;
+
 constexpr int kBlkLongWq = 8;       // BlockItem::wq of a long block
 // Local zoom items: BlockItem::wq = wq + 16 log2(D) -- reach group wq, coarse grid of 4096 / D samples per block (D = 4:
 // filter spectra of <= 256 - 16 bins, groups of 4 bands; D = 8: <= 128 - 16 bins, groups of 8 bands)
@@ -152,7 +156,7 @@ struct BlockArgs {
   const cplx<T>* edge_bank;     // [nsplit][2][kBlk]
   const cplx<T>* edge_part;     // [C][nsplit][n]: the zoom engine's part of the split bands
   const BlockItem* items;  // [nitems + nedge_items] device, most expensive first
-  const BlockBand* bands;  // device, all reach groups
+  const BlockBandT<T>* bands;  // device, all reach groups
   const cplx<T>* bank;     // [rows][kBlk], scaled by 1 / kBlk
   const float* lz_w;       // local zoom: [2][8][kBlkLzTaps] interpolation weights for D = 4 and D = 8 (lz_weights)
   const T* sig;            // [C][n]

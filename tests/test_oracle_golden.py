@@ -286,3 +286,28 @@ def test_benchmark_length_rows(golden, order, name):
     assert np.array_equal(fc, g[f"chirp_f_o{order}"])
     ref = g[f"chirp_rows_o{order}"][pick_c]
     assert np.max(np.abs(c[:, tsel] - ref)) <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,log2n,order,dtype,channel,transforms", [
+    ("large_n1048576_f64.npz", 20, 3, np.float64, (0, 1), ("cwt", "stx")),
+    ("large_n1048576_o12_ch63_stx.npz", 20, 12, np.float32, (63, 64), ("stx",)),
+    ("large_n524288_o6.npz", 19, 6, np.float32, (0, 1), ("cwt", "stx")),
+])
+def test_round3_fixtures_rows(golden, name, log2n, order, dtype, channel, transforms):
+    """The oracle against the reference rows added in round 3: the benchmark record in float64 (the reference then works
+    in double throughout), channel 63 of the BASELINE configs[2] batch (Stockwell), and an order-6 table at 2^19."""
+    g = golden(name)
+    n, fs = 1 << log2n, 1000.0
+    sig = orc.synth_chirp(n, fs, channel[0], channel[1], dtype=dtype)
+    assert np.array_equal(sig[:: n // 4096], g["sig_samples"])
+    n_b = len(g[f"f_o{order}"])
+    pick = sorted({0, n_b // 3, (2 * n_b) // 3, n_b - 1})
+    for name_t, fn in (("cwt", orc.cwt_fft), ("stx", orc.stx_fft)):
+        if name_t not in transforms:
+            continue
+        tsel = g[f"{name_t}_tsel_o{order}"]
+        f, _, panel = fn(order, sig, fs, bands=pick)
+        assert np.array_equal(f, g[f"f_o{order}"])
+        ref = g[f"{name_t}_rows_o{order}"][pick]
+        assert np.max(np.abs(panel[:, tsel] - ref)) <= 1e-12 * np.abs(ref).max()
+        assert np.allclose((np.abs(panel) ** 2).sum(axis=1), g[f"{name_t}_psum_band_o{order}"][pick], rtol=1e-11)
