@@ -354,8 +354,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
         const T kf0 = (T)(col - bd.kappa_int), cwf = -(T)bd.cw * (T)bd.kappa_frac, cw = (T)bd.cw, la = (T)bd.la;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-          const T e = fmaf(cw, kf0 + (T)(256 * b), cwf);
-          const T r = fast_exp2(fmaf(-e, e, la));
+          const T e = fma_t(cw, kf0 + (T)(256 * b), cwf);
+          const T r = fast_exp2(fma_t(-e, e, la));
           v[b] = mk<T>(S[b].x * r, S[b].y * r);
         }
         if (lower) {
@@ -364,8 +364,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
         } else {
 #pragma unroll
           for (int b = 8; b < 16; ++b) {
-            const T e = fmaf(cw, kf0 + (T)(256 * b), cwf);
-            const T r = fast_exp2(fmaf(-e, e, la));
+            const T e = fma_t(cw, kf0 + (T)(256 * b), cwf);
+            const T r = fast_exp2(fma_t(-e, e, la));
             v[b] = mk<T>(S[b].x * r, S[b].y * r);
           }
         }

@@ -63,6 +63,8 @@ __device__ __forceinline__ double2 cmul_rn(double2 a, double2 b) {
   return make_double2(fma(a.x, b.x, -__dmul_rn(a.y, b.y)), fma(a.x, b.y, __dmul_rn(a.y, b.x)));
 }
 
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float log2_t(float v) { return log2f(v); }
 __device__ __forceinline__ double log2_t(double v) { return log2(v); }
 __device__ __forceinline__ float sqrt_t(float v) { return sqrtf(v); }
