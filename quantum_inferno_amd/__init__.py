@@ -1,9 +1,15 @@
-"""Import shim: the package lives in the directory `quantum-inferno_amd/`, which is not a valid
-Python identifier.  `import quantum_inferno_amd` resolves every submodule from there."""
-import os as _os
+"""
+quantum-inferno TFR hot path, MI355X-native.
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "quantum-inferno_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _fh:
-    exec(compile(_fh.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _fh, _real
+Drop-in for the FFT-based time-frequency stack of ISLA-UH/quantum-inferno: same module and
+function names (styx_fft, styx_cwt, styx_stx, cwt_atoms, tfr_info over scales_dyadic bands),
+computed by hand-written HIP kernels for gfx950 behind a C ABI (include/qi_tfr.h).
+There is no CPU fallback: transforms raise if libqi_tfr.so or a HIP device is missing.
+"""
+from . import scales_dyadic  # noqa: F401  (host tables; importable without a GPU)
+from . import utilities  # noqa: F401
+from . import _lib, engine  # noqa: F401
+from . import styx_fft, styx_cwt, styx_stx, cwt_atoms, tfr_info  # noqa: F401
+from .engine import PlanRing, TfrPlan, TfrResult  # noqa: F401
+
+__version__ = "0.1.0"

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libqi_tfr.so")
-SOURCES = ["qi_api.hip", "qi_kernels.hip", "qi_native.hip", "qi_block.hip", "qi_zoom.hip", "qi_shannon1d.hip", "qi_stft_sliding.hip", "qi_stft_fused.hip", "qi_zoom64.hip"]
+SOURCES = ["qi_api.hip", "qi_api_ops.hip", "qi_host_util.hip", "qi_plan_build.hip", "qi_run.hip", "qi_kernels.hip", "qi_native.hip", "qi_block.hip", "qi_zoom.hip", "qi_shannon1d.hip", "qi_stft_sliding.hip", "qi_stft_fused.hip", "qi_zoom64.hip"]
 ARCH = "gfx950"
 # the FFT kernels lose ~10 % to the register shuffles of SLP-packed v_pk_* arithmetic (no throughput gain on gfx950)
 PER_FILE_FLAGS = {"qi_native.hip": ("-fno-slp-vectorize",), "qi_block.hip": ("-fno-slp-vectorize",), "qi_zoom.hip": ("-fno-slp-vectorize",)}

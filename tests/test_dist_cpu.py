@@ -1,5 +1,5 @@
 """world_size-2 `gloo` test of the multi-GPU leg on CPU: contiguous channel sharding and the single
-gather of the reduced TFR product to rank 0 (quantum-inferno_amd/dist.py)."""
+gather of the reduced TFR product to rank 0 (quantum_inferno_amd/dist.py)."""
 import os
 import socket
 import sys

@@ -102,7 +102,7 @@ def test_no_cpu_fallback():
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "quantum-inferno_amd")
+    pkg = os.path.join(ROOT, "quantum_inferno_amd")
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith((".py", ".hip", ".hpp", ".h")):
@@ -132,7 +132,7 @@ def test_stream_chunking_cursor():
 
 def test_sliding_stft_geometry_matches_scipy():
     """The host restatement of scipy.signal.ShortTimeFFT's slice geometry and canonical dual window
-    (quantum-inferno_amd/utilities/short_time_fft.py: TukeyStft) against SciPy itself over a sweep of shapes."""
+    (quantum_inferno_amd/utilities/short_time_fft.py: TukeyStft) against SciPy itself over a sweep of shapes."""
     import scipy.signal as ss
 
     from quantum_inferno_amd.utilities import short_time_fft as stf

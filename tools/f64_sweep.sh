@@ -7,4 +7,4 @@ import json,sys
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['step_roofline']['stage_ms_per_step'])"; }
 run A=1
 run3 A=1
-run QI_TFR_LIB=$PWD/quantum-inferno_amd/libqi_tfr_u1w4.so
+run QI_TFR_LIB=$PWD/quantum_inferno_amd/libqi_tfr_u1w4.so

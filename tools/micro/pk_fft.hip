@@ -1,5 +1,5 @@
 // Micro-benchmark: register FFT16 + 15 twiddle multiplies per iteration, scalar f32 code vs packed (v_pk_*_f32) code.
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I ../../include -I ../../quantum-inferno_amd/csrc pk_fft.hip -o pk_fft
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -I ../../include -I ../../quantum_inferno_amd/csrc pk_fft.hip -o pk_fft
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <utility>

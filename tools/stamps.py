@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: run one transform with the stamped library (python quantum-inferno_amd/_build.py --stamps) and let it
+"""Diagnostic: run one transform with the stamped library (python quantum_inferno_amd/_build.py --stamps) and let it
 print the mean cycles each block / pass-2 workgroup spent per phase (at plan destruction).
 usage: QI_TUNE=1 QI_TFR_LIB=.../libqi_tfr_stamps.so QI_NATIVE_STAMPS=1 python tools/stamps.py [cwt|stx] [order] [channels]"""
 import os, sys
