@@ -197,6 +197,7 @@ int qi_plan_set_gabor_bank(qi_plan* p, int bank, int32_t B, const double* p_re, 
   QI_REQUIRE(bank == QI_BANK_STYX || bank == QI_BANK_ATOMS, "bad bank %d", bank);
   QI_REQUIRE(B > 0 && B <= 65535, "band count %d out of range", B);
   DeviceGuard g(p->d.device);
+  p->table_gen++;
   hipStream_t st = (hipStream_t)stream;
   const int64_t L = bank == QI_BANK_ATOMS ? p->n : p->L;
   const size_t esz = p->d.dtype == QI_F64 ? sizeof(double2) : sizeof(float2);
@@ -343,6 +344,7 @@ int qi_plan_set_stx_bands(qi_plan* p, int32_t B, const int64_t* shift_index, con
     QI_REQUIRE(shift_index[j] >= 0 && shift_index[j] < p->n, "shift_index[%d] = %lld outside [0, n)", j,
                (long long)shift_index[j]);
   DeviceGuard g(p->d.device);
+  p->table_gen++;
   if (p->d_stx_idx) {
     QI_HIP(hipDeviceSynchronize());
     QI_HIP(hipFree(p->d_stx_idx));
@@ -463,13 +465,27 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
     DeviceGuard g0(p->d.device);
     int64_t tile = C;
     if (p->native_tile > 0 && tile > p->native_tile) tile = p->native_tile;
-    for (int it = 0; it < 8 && tile >= 1; ++it) {
-      size_t pc0 = 0, pc2 = 0;
-      QI_TRY(run_native<float>(p, bank, sig, tile, out_cwt, st, false, &p->carry, nullptr, &pc0));
-      QI_TRY(run_native<float>(p, 2, sig, tile, out_stx, st, true, nullptr, &p->carry, &pc2));
-      const int64_t fit = p->ws_bytes > (1u << 16) ? (int64_t)((p->ws_bytes - (1u << 16)) / (pc0 + pc2)) : 0;
-      if (fit >= tile) break;
-      tile = fit;
+    // (the settled size is kept per request shape: the probes are pure host work, but a step of one record is a quarter
+    // of a millisecond)
+    auto want = [](const qi_tfr_out* o) {
+      return (o->coef ? 1u : 0u) | (o->bits ? 2u : 0u) | (o->power_band ? 4u : 0u) | (o->power_time ? 8u : 0u) | (o->stats ? 16u : 0u);
+    };
+    const unsigned flags = want(out_cwt) | (want(out_stx) << 8);
+    if (p->tile_cache.C == C && p->tile_cache.flags == flags && p->tile_cache.gen == p->table_gen) {
+      tile = p->tile_cache.tile;
+    } else {
+      for (int it = 0; it < 8 && tile >= 1; ++it) {
+        size_t pc0 = 0, pc2 = 0;
+        QI_TRY(run_native<float>(p, bank, sig, tile, out_cwt, st, false, &p->carry, nullptr, &pc0));
+        QI_TRY(run_native<float>(p, 2, sig, tile, out_stx, st, true, nullptr, &p->carry, &pc2));
+        const int64_t fit = p->ws_bytes > (1u << 16) ? (int64_t)((p->ws_bytes - (1u << 16)) / (pc0 + pc2)) : 0;
+        if (fit >= tile) break;
+        tile = fit;
+      }
+      p->tile_cache.C = C;
+      p->tile_cache.flags = flags;
+      p->tile_cache.gen = p->table_gen;
+      p->tile_cache.tile = tile;
     }
     if (tile >= 1) {
       const int64_t n = p->n, B0 = p->nb[bank], B2 = p->nb_stx;

@@ -290,6 +290,13 @@ struct qi_plan {
       *this = BlockTable();
     }
   } blk[3];
+  // qi_cwt_stx: the settled tile (records per joint tile) of the last request shape; any table change bumps table_gen
+  struct {
+    int64_t C = -1, tile = 0;
+    unsigned flags = 0;
+    uint64_t gen = 0;
+  } tile_cache;
+  uint64_t table_gen = 1;
   int native_block = 1;        // use the block engine for short-atom bands (0: two-pass paths only)
   // qi_cwt_stx: the CWT leaves the zero-padded spectra of the records at the start of the scratch
   const void* shared_sig = nullptr;
