@@ -6,6 +6,32 @@ namespace qi {
 
 constexpr int kWave = 64;
 
+// Wave-wide reductions without the LDS crossbar: four DPP steps inside each row of sixteen lanes (quad permutes, half-row
+// and row mirrors: afterwards every lane of a row holds the row's result), then the four rows by v_readlane.  The total is
+// returned in EVERY lane; the order of the additions is fixed.  (The __shfl_down tree this replaces is twelve
+// ds_bpermute_b32 for a double, each a round trip through the LDS pipe in a dependent chain -- once per band and wave in
+// the block, zoom and two-pass kernels.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+#ifdef QI_WAVE_SHFL  // (A/B: the shuffle trees of rounds 1-2)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -21,6 +47,30 @@ __device__ __forceinline__ T wave_max(T v) {
   }
   return v;
 }
+#else
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+  T w = dpp_mov<0xB1>(v);
+  v = w > v ? w : v;
+  w = dpp_mov<0x4E>(v);
+  v = w > v ? w : v;
+  w = dpp_mov<0x141>(v);
+  v = w > v ? w : v;
+  w = dpp_mov<0x140>(v);
+  v = w > v ? w : v;
+  const T a = lane_get(v, 0), b = lane_get(v, 16), c = lane_get(v, 32), d = lane_get(v, 48);
+  const T ab = b > a ? b : a, cd = d > c ? d : c;
+  return cd > ab ? cd : ab;
+}
+#endif
 
 // streaming stores of panel data that is never read back by this launch (nontemporal: no allocation in the caches)
 typedef float qi_f2 __attribute__((ext_vector_type(2)));
