@@ -452,7 +452,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           z[h] = v[brev(i + h + WQ, 4)];
-          if (DEMOD) {
+          if (DEMOD && !QI_BDBG(32)) {
             if (i + h > 0) {
               if (((i + h) & 3) == 0) {
                 seed = cmul_rn(seed, R4);
@@ -477,7 +477,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
           col_p[i + h] += p;
           rowacc += p;
           mx = max_t(mx, p);
-          pl += plog2p(p);
+          if (!QI_BDBG(16)) pl += plog2p(p);
         }
         if (COEF && inside && !QI_BDBG(1)) store_pair(coef_row, tt, z[0], z[1]);
         if (BITS && inside) store_real_pair(bits_row, tt, lg[0], lg[1]);
@@ -486,7 +486,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     if (t0 + W + V > n) finish_band(std::true_type{});
     else finish_band(std::false_type{});
     plogp += (double)pl;
-    if (a.part_band) {
+    if (a.part_band && !QI_BDBG(64)) {
       const double r = wave_sum((double)rowacc);
       if (lane == 0) s_red[par][wv] = r;
       pending = bd.out_band;
