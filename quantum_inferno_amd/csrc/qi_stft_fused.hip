@@ -41,13 +41,6 @@ __device__ __forceinline__ cplx<T> csub(cplx<T> a, cplx<T> b) {
   return mk<T>(a.x - b.x, a.y - b.y);
 }
 
-// complex elements of one segment's tile: R rows of C + 1, padded so that TILE = 4 (mod 16): in the untangling pass the lanes
-// of a 32-lane group read bins k .. k + 7 (bank pairs 2 k apart) of four segments 2 TILE apart -- sixty-four different banks
-constexpr int stft_tile(int log2r, int log2c) {
-  const int body = (1 << log2r) * ((1 << log2c) + 1);
-  return body + ((4 - body % 16) + 16) % 16;
-}
-
 struct StftFusedArgs {
   int64_t n, seg, hop, nseg, lead;  // lead: zero-extended samples in front of the record (seg / 2 for the STFT, 0 Welch)
   int32_t log2g, G;                 // G = 1 << log2g segments per workgroup
@@ -67,7 +60,7 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
                                                             cplx<T>* __restrict__ Z, T* __restrict__ bits,
                                                             StftFusedArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  constexpr int R = 1 << LOG2R, C = 1 << LOG2C, M = R * C, RS = C + 1, TILE = stft_tile(LOG2R, LOG2C);
+  constexpr int R = 1 << LOG2R, C = 1 << LOG2C, M = R * C, RS = C + 1, TILE = R * RS + 1;
   const int G = a.G;
   cplx<T>* __restrict__ data = reinterpret_cast<cplx<T>*>(lds_raw);
   cplx<T>* __restrict__ tw = data + (size_t)G * TILE;
@@ -100,23 +93,15 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
     constexpr int NP = (M + kWave - 1) / kWave;
     T v0[NP], v1[NP];
     double acc = 0.0;
-    // (pairs as one 2 sizeof(T)-byte load when the segment starts on an even sample of an even-length record)
-    const bool pairs = ((base | a.n) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & (2 * sizeof(T) - 1)) == 0;
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int64_t i0 = 2 * (int64_t)(lane + kWave * t), k0 = base + i0;
-      if (pairs) {
-        cplx<T> xv = mk<T>(T(0), T(0));
-        if (i0 < a.seg && k0 >= 0 && k0 < a.n) xv = *reinterpret_cast<const cplx<T>*>(x + k0);
-        v0[t] = xv.x;
-        v1[t] = i0 + 1 < a.seg ? xv.y : T(0);
-      } else {
-        v0[t] = (i0 < a.seg && k0 >= 0 && k0 < a.n) ? x[k0] : T(0);
-        v1[t] = (i0 + 1 < a.seg && k0 + 1 >= 0 && k0 + 1 < a.n) ? x[k0 + 1] : T(0);
-      }
+      v0[t] = (i0 < a.seg && k0 >= 0 && k0 < a.n) ? x[k0] : T(0);
+      v1[t] = (i0 + 1 < a.seg && k0 + 1 >= 0 && k0 + 1 < a.n) ? x[k0 + 1] : T(0);
       acc += (double)v0[t] + (double)v1[t];
     }
     acc = wave_sum(acc);
+    acc = __shfl(acc, 0, kWave);
     const T mean = (T)(acc / (double)a.seg);
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
@@ -162,48 +147,26 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   __syncthreads();
 
   // untangle and store: X[k] = (Z[k] + conj Z[M-k]) / 2 - (i / 2) exp(-i pi k / M) (Z[k] - conj Z[M-k]), Z[M] = Z[0];
-  // Z[k] = row k mod R, column k / R.  One work item = the bin PAIR (k, M - k), k = 0 .. M / 2, of a segment PAIR: with
-  // e = (Z[k] + conj Z[M-k]) / 2 and u = exp(-i pi k / M) (Z[k] - conj Z[M-k]) / 2,  X[k] = e - i u  and  X[M-k] = conj(e + i u)
-  // -- one pair of LDS reads, one twiddle and one complex product for two coefficients --, and the two segments of a bin are
-  // adjacent in memory: one 2 sizeof(complex) store.  Consecutive threads take consecutive segment pairs of one bin pair.
+  // Z[k] = row k mod R, column k / R.  Consecutive threads take consecutive segments of one bin.
   const int nf = M + 1, lg = a.log2g;
   const T scale = (T)a.scale, eps = (T)a.eps;
-  cplx<T>* __restrict__ Zc = Z + (size_t)c * nf * a.nseg;
-  T* __restrict__ Bc = bits ? bits + (size_t)c * nf * a.nseg : nullptr;
-  const uint32_t nseg = (uint32_t)a.nseg;
-  auto put = [&](uint32_t at, cplx<T> x0, cplx<T> x1, bool two) {
-    if (two) {
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(Zc + at) = make_float4(x0.x, x0.y, x1.x, x1.y);  // (8-byte aligned: the hardware splits odd rows)
-      } else {
-        Zc[at] = x0;
-        Zc[at + 1] = x1;
-      }
-      if (Bc) {
-        Bc[at] = log2_t(sqrt_t(x0.x * x0.x + x0.y * x0.y) + eps);
-        Bc[at + 1] = log2_t(sqrt_t(x1.x * x1.x + x1.y * x1.y) + eps);
-      }
-    } else {
-      Zc[at] = x0;
-      if (Bc) Bc[at] = log2_t(sqrt_t(x0.x * x0.x + x0.y * x0.y) + eps);
-    }
-  };
-  // Consecutive threads take consecutive segments of one bin, bins in ascending order (a workgroup's stores then walk the
-  // panel rows once, front to back: pairing the bins k and M - k in one work item -- one product for two coefficients --
-  // and pairing segments for 16-byte stores were both measured 25 % SLOWER: the kernel is bound by the order and the
-  // number of rows its store instructions touch, not by its arithmetic)
   for (int q = tid; q < (nf << lg); q += kStftThreads) {
     const int k = q >> lg, g = q & (G - 1);
-    const uint32_t m = (uint32_t)m0 + (uint32_t)g;
-    if (m >= nseg) continue;
+    const int64_t m = m0 + g;
+    if (m >= a.nseg) continue;
     const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
     const int ka = k & (M - 1), kb = (M - k) & (M - 1);
     const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
     const cplx<T> e = mk<T>(T(0.5) * (za.x + zb.x), T(0.5) * (za.y - zb.y));   // (Z[k] + conj Z[M-k]) / 2
     const cplx<T> o = mk<T>(T(0.5) * (za.x - zb.x), T(0.5) * (za.y + zb.y));   // (Z[k] - conj Z[M-k]) / 2
     const cplx<T> w = k < M ? tw[k] : mk<T>(T(-1), T(0));
-    const cplx<T> u = cmul(o, w);
-    put((uint32_t)k * nseg + m, mk<T>((e.x + u.y) * scale, (e.y - u.x) * scale), mk<T>(T(0), T(0)), false);  // e - i u
+    const cplx<T> wo = cmul(o, w);
+    cplx<T> X = mk<T>(e.x + wo.y, e.y - wo.x);  // e - i (w o)
+    X.x *= scale;
+    X.y *= scale;
+    const int64_t at = (c * nf + k) * a.nseg + m;
+    Z[at] = X;
+    if (bits) bits[at] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
   }
 }
 
@@ -221,7 +184,7 @@ static bool stft_shape(int64_t M, int* lr, int* lc) {
 
 // segments per workgroup (a power of two <= 16) so that the tiles and the twiddles stay within `budget` bytes of LDS
 static int stft_fused_group(int64_t M, int lr, int lc, size_t esz, size_t budget) {
-  const size_t tile = (size_t)stft_tile(lr, lc);
+  const size_t tile = ((size_t)1 << lr) * (((size_t)1 << lc) + 1) + 1;
   for (int G = 16; G >= 1; G >>= 1)
     if (((size_t)G * tile + M) * esz <= budget) return G;
   return 0;
@@ -247,7 +210,7 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
   a.G = G;
   a.log2g = 0;
   while ((1 << a.log2g) < G) ++a.log2g;
-  const size_t tile = (size_t)stft_tile(LR, LC);
+  const size_t tile = ((size_t)1 << LR) * (((size_t)1 << LC) + 1) + 1;
   const size_t lds = ((size_t)G * tile + M) * sizeof(cplx<T>);
   QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>), lds));
   a.ngroups = (int32_t)ceil_div(nseg, G);
