@@ -19,7 +19,10 @@ namespace qi {
 
 namespace {
 
-constexpr int kStftThreads = 256;
+#ifndef QI_STFT_THREADS
+#define QI_STFT_THREADS 256
+#endif
+constexpr int kStftThreads = QI_STFT_THREADS;
 
 template <typename T>
 __device__ __forceinline__ void sincospi_t(T x, T* s, T* c);

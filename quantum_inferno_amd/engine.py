@@ -481,9 +481,31 @@ def finish(result_tensor, was_numpy, was_1d, widen=False):
         with torch.cuda.device(t.device):
             _lib.check(_lib.load().qi_widen(t.device.index, _lib.ptr(src), _lib.ptr(wide), src.numel(), _lib.stream_ptr(t.device)))
         t = wide
-    if t.numel() * t.element_size() >= (1 << 20):
-        return _staged_copy(t)
+    nbytes = t.numel() * t.element_size()
+    if nbytes >= PINNED_RESULT_MAX_BYTES:
+        return _staged_copy(t)  # bounded page-locked memory: two 64 MiB staging buffers, pageable result
+    if nbytes >= (1 << 20):
+        # the result itself in page-locked memory: one copy at PCIe speed.  PyTorch's pinned allocator keeps freed blocks
+        # page-locked, so what it has cached is handed back to the system once it exceeds the cap.
+        _trim_pinned_cache()
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t)
+        return host.numpy()
     return t.cpu().numpy()
+
+
+PINNED_RESULT_MAX_BYTES = 4 << 30  # larger results are staged through two fixed buffers into pageable memory
+
+
+def _trim_pinned_cache():
+    """Return cached (freed, still page-locked) host blocks to the system when they exceed PINNED_RESULT_MAX_BYTES."""
+    try:
+        stats = torch.cuda.memory.host_memory_stats()
+        cached = int(stats.get("allocated_bytes.current", 0)) - int(stats.get("active_bytes.current", 0))
+        if cached > PINNED_RESULT_MAX_BYTES:
+            torch._C._host_emptyCache()
+    except Exception:  # (older PyTorch: no host allocator statistics -- nothing to trim with)
+        pass
 
 
 _STAGE_BYTES = 64 << 20
