@@ -36,6 +36,10 @@ int welch_impl(int device, const void* sig, int64_t C, int64_t n, const void* wi
                int64_t nfft, double scale, void* pxx, char* scratch, hipStream_t st) {
   const int64_t nseg = (n - seg) / hop + 1;
   const int64_t nf = nfft / 2 + 1;
+  static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
+  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft))  // segments, transform, |X|^2 sums in one kernel
+    return launch_welch_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<T*>(pxx),
+                                 reinterpret_cast<double*>(scratch), C, n, seg, hop, nfft, nseg, scale * scale, st);
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,

@@ -161,7 +161,12 @@ int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t
 bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft);
 template <typename T>
 int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
-                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st);
+                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st,
+                      double* welch_part = nullptr, int32_t* ngroups_out = nullptr);
+// Welch mean on the fused kernel (`part`: [C][<= nseg][nfft / 2 + 1] doubles of scratch)
+template <typename T>
+int launch_welch_fused(const T* sig, const T* win, T* pxx, double* part, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                       int64_t nfft, int64_t nseg, double scale2, hipStream_t st);
 template <typename T>
 int launch_welch_mean(const cplx<T>* F, T* pxx, int64_t C, int64_t nseg, int64_t nf, int64_t nfft, T scale2,
                       hipStream_t st);

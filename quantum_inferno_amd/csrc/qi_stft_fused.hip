@@ -50,6 +50,7 @@ struct StftFusedArgs {
   int32_t ngroups, per_xcd;         // segment groups per record; work items (record, group) per XCD
   int64_t nitems;                   // records x groups
   double scale, eps;
+  double* welch_part;  // Welch (welch_power_pow2): [C][ngroups][nfft / 2 + 1] sums of |X|^2 over a group's segments; no panel
 };
 
 // dynamic LDS: data [G][R (C + 1) + 1] complex | twiddles [M] complex (exp(-2 pi i k / (2 M)))
@@ -153,6 +154,27 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   // Z[k] = row k mod R, column k / R.  Consecutive threads take consecutive segments of one bin.
   const int nf = M + 1, lg = a.log2g;
   const T scale = (T)a.scale, eps = (T)a.eps;
+  if (a.welch_part) {
+    // Welch mean (styx_fft.py:230-266): the sum over this workgroup's segments of |X[k]|^2, one partial per (record,
+    // group, bin); k_welch_reduce adds the groups in index order
+    double* __restrict__ part = a.welch_part + ((size_t)c * a.ngroups + (size_t)(item % a.ngroups)) * nf;
+    for (int k = tid; k < nf; k += kStftThreads) {
+      const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+      const cplx<T> w = k < M ? tw[k] : mk<T>(T(-1), T(0));
+      double acc = 0.0;
+      for (int g = 0; g < G && m0 + g < a.nseg; ++g) {
+        const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
+        const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
+        const cplx<T> e = mk<T>(T(0.5) * (za.x + zb.x), T(0.5) * (za.y - zb.y));
+        const cplx<T> o = mk<T>(T(0.5) * (za.x - zb.x), T(0.5) * (za.y + zb.y));
+        const cplx<T> wo = cmul(o, w);
+        const T xr = e.x + wo.y, xi = e.y - wo.x;
+        acc += (double)(xr * xr + xi * xi);
+      }
+      part[k] = acc;
+    }
+    return;
+  }
   for (int q = tid; q < (nf << lg); q += kStftThreads) {
     const int k = q >> lg, g = q & (G - 1);
     const int64_t m = m0 + g;
@@ -171,6 +193,19 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
     Z[at] = X;
     if (bits) bits[at] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
   }
+}
+
+// Pxx[c][f] = w_f scale^2 / nseg * sum over the groups (index order) of their partial sums, w_f = 2 except at DC and Nyquist
+template <typename T>
+__global__ void k_welch_reduce(const double* __restrict__ part, T* __restrict__ pxx, int ngroups, int64_t nseg, int nf,
+                               T scale2) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t c = blockIdx.y;
+  if (f >= nf) return;
+  double acc = 0.0;
+  for (int g = 0; g < ngroups; ++g) acc += part[((size_t)c * ngroups + g) * nf + f];
+  const bool paired = f > 0 && f != nf - 1;  // (nfft is even here)
+  pxx[c * nf + f] = (T)(acc / (double)nseg) * scale2 * (paired ? T(2) : T(1));
 }
 
 }  // namespace
@@ -199,6 +234,8 @@ bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft) {
   return dtype == QI_F64 ? stft_shape<double>(nfft / 2, &lr, &lc) : stft_shape<float>(nfft / 2, &lr, &lc);
 }
 
+static thread_local int32_t g_last_ngroups = 0;  // segment groups per record of this thread's last launch (Welch partials)
+
 template <typename T, int LR, int LC>
 static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t nseg, StftFusedArgs a,
                              hipStream_t st) {
@@ -217,6 +254,7 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
   const size_t lds = ((size_t)G * tile + M) * sizeof(cplx<T>);
   QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>), lds));
   a.ngroups = (int32_t)ceil_div(nseg, G);
+  g_last_ngroups = a.ngroups;
   a.nitems = (int64_t)a.ngroups * C;
   a.per_xcd = (int32_t)ceil_div(a.nitems, 8);
   dim3 grid((unsigned)(8 * a.per_xcd));
@@ -227,8 +265,11 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
 
 template <typename T>
 int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
-                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st) {
+                      int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st,
+                      double* welch_part, int32_t* ngroups_out) {
   StftFusedArgs a;
+  a.welch_part = welch_part;
+  (void)ngroups_out;
   a.n = n;
   a.seg = seg;
   a.hop = hop;
@@ -259,8 +300,25 @@ int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C
 }
 
 template int launch_stft_fused<float>(const float*, const float*, float2*, float*, int64_t, int64_t, int64_t, int64_t,
-                                      int64_t, int64_t, int64_t, double, double, hipStream_t);
+                                      int64_t, int64_t, int64_t, double, double, hipStream_t, double*, int32_t*);
 template int launch_stft_fused<double>(const double*, const double*, double2*, double*, int64_t, int64_t, int64_t, int64_t,
-                                       int64_t, int64_t, int64_t, double, double, hipStream_t);
+                                       int64_t, int64_t, int64_t, double, double, hipStream_t, double*, int32_t*);
+
+// Welch power spectrum on the fused kernel: partial sums per segment group in `part` ([C][groups][nfft / 2 + 1] doubles,
+// groups <= nseg), then the mean over the segments with scipy's one-sided "spectrum" weights
+template <typename T>
+int launch_welch_fused(const T* sig, const T* win, T* pxx, double* part, int64_t C, int64_t n, int64_t seg, int64_t hop,
+                       int64_t nfft, int64_t nseg, double scale2, hipStream_t st) {
+  QI_TRY(launch_stft_fused<T>(sig, win, nullptr, nullptr, C, n, seg, hop, nfft, nseg, 0, 1.0, 0.0, st, part, nullptr));
+  const int nf = (int)(nfft / 2 + 1);
+  dim3 g((unsigned)ceil_div(nf, 256), (unsigned)C);
+  k_welch_reduce<T><<<g, 256, 0, st>>>(part, pxx, g_last_ngroups, nseg, nf, (T)scale2);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+template int launch_welch_fused<float>(const float*, const float*, float*, double*, int64_t, int64_t, int64_t, int64_t, int64_t,
+                                       int64_t, double, hipStream_t);
+template int launch_welch_fused<double>(const double*, const double*, double*, double*, int64_t, int64_t, int64_t, int64_t,
+                                        int64_t, int64_t, double, hipStream_t);
 
 }  // namespace qi
