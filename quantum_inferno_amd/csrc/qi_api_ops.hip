@@ -59,6 +59,12 @@ int sliding_stft_impl(int device, const T* sig, int64_t C, int64_t n, const T* w
                       int64_t nfft, int64_t first, int64_t nseg, int pad_mode, int detrend, int64_t roll, cplx<T>* Z, T* R,
                       int kind, char* scratch, hipStream_t st) {
   const int64_t nf = nfft / 2 + 1;
+  static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
+  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft)) {
+    // one kernel: slices (padding mode, optional detrend), transform, phase roll, [frequency][slice] store
+    const StftSliding sl{pad_mode, detrend, R ? kind : 0, roll};
+    return launch_stft_fused<T>(sig, window, Z, R, C, n, seg, hop, nfft, nseg, -first, 1.0, 0.0, st, nullptr, &sl);
+  }
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_sliding_frames<T>(sig, window, frames, C, n, seg, hop, nfft, nseg, first, pad_mode, detrend, roll, st));

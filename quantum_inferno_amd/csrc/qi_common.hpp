@@ -157,12 +157,18 @@ int launch_finalize(const double* part_band, const double* part_stat, double* po
 template <typename T>
 int launch_stft_frames(const T* sig, const T* win, T* frames, int64_t C, int64_t n, int64_t seg, int64_t hop,
                        int64_t nfft, int64_t nseg, int64_t lead, hipStream_t st);
+// options of scipy.signal.ShortTimeFFT's convention on the fused STFT kernel (qi_sliding_stft): record extension past its
+// ends (0 zeros, 1 edge, 2 / 3 even / odd reflection), mean removal, left rotation of the slice, real output (1 |X|, 2 |X|^2)
+struct StftSliding {
+  int32_t pad_mode, detrend, real_kind;
+  int64_t roll;
+};
 // fused STFT (qi_stft_fused.hip): frames, transform and [frequency][time] store in one kernel
 bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft);
 template <typename T>
 int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
                       int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st,
-                      double* welch_part = nullptr, int32_t* ngroups_out = nullptr);
+                      double* welch_part = nullptr, const StftSliding* sliding = nullptr);
 // Welch mean on the fused kernel (`part`: [C][<= nseg][nfft / 2 + 1] doubles of scratch)
 template <typename T>
 int launch_welch_fused(const T* sig, const T* win, T* pxx, double* part, int64_t C, int64_t n, int64_t seg, int64_t hop,

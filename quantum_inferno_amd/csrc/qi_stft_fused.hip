@@ -44,6 +44,17 @@ __device__ __forceinline__ cplx<T> csub(cplx<T> a, cplx<T> b) {
   return mk<T>(a.x - b.x, a.y - b.y);
 }
 
+// sample k of the record extended past its ends (np.pad: constant 0 / edge / reflect even / odd; qi_stft_sliding.hip)
+template <typename T>
+__device__ __forceinline__ T stft_sample(const T* __restrict__ x, int64_t n, int64_t k, int mode) {
+  if (k >= 0 && k < n) return x[k];
+  if (mode == 0) return T(0);
+  if (mode == 1) return k < 0 ? x[0] : x[n - 1];
+  const int64_t j = k < 0 ? -k : 2 * (n - 1) - k;
+  if (mode == 2) return x[j];
+  return T(2) * (k < 0 ? x[0] : x[n - 1]) - x[j];
+}
+
 struct StftFusedArgs {
   int64_t n, seg, hop, nseg, lead;  // lead: zero-extended samples in front of the record (seg / 2 for the STFT, 0 Welch)
   int32_t log2g, G;                 // G = 1 << log2g segments per workgroup
@@ -51,6 +62,12 @@ struct StftFusedArgs {
   int64_t nitems;                   // records x groups
   double scale, eps;
   double* welch_part;  // Welch (welch_power_pow2): [C][ngroups][nfft / 2 + 1] sums of |X|^2 over a group's segments; no panel
+  // scipy.signal.ShortTimeFFT's convention (qi_sliding_stft): how the record is extended past its ends (0 zeros, 1 edge
+  // values, 2 / 3 even / odd reflection), whether the slice's mean is removed, the left rotation of the windowed slice
+  // (a phase ramp exp(2 pi i k roll / nfft) on the coefficients) and what the real output holds (0: log2 bits, 1: |X|,
+  // 2: |X|^2)
+  int32_t pad_mode, detrend, real_kind;
+  int64_t roll;
 };
 
 // dynamic LDS: data [G][R (C + 1) + 1] complex | twiddles [M] complex (exp(-2 pi i k / (2 M)))
@@ -100,13 +117,12 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int64_t i0 = 2 * (int64_t)(lane + kWave * t), k0 = base + i0;
-      v0[t] = (i0 < a.seg && k0 >= 0 && k0 < a.n) ? x[k0] : T(0);
-      v1[t] = (i0 + 1 < a.seg && k0 + 1 >= 0 && k0 + 1 < a.n) ? x[k0 + 1] : T(0);
+      v0[t] = i0 < a.seg ? stft_sample<T>(x, a.n, k0, a.pad_mode) : T(0);
+      v1[t] = i0 + 1 < a.seg ? stft_sample<T>(x, a.n, k0 + 1, a.pad_mode) : T(0);
       acc += (double)v0[t] + (double)v1[t];
     }
     acc = wave_sum(acc);
-    acc = __shfl(acc, 0, kWave);
-    const T mean = (T)(acc / (double)a.seg);
+    const T mean = a.detrend ? (T)(acc / (double)a.seg) : T(0);
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int j = lane + kWave * t;
@@ -189,9 +205,17 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
     cplx<T> X = mk<T>(e.x + wo.y, e.y - wo.x);  // e - i (w o)
     X.x *= scale;
     X.y *= scale;
+    if (a.roll) {  // the slice rotated left by `roll` samples: X[k] exp(2 pi i k roll / nfft), phase from the table (exact index)
+      const int j = (int)(((int64_t)k * a.roll) & (2 * M - 1));
+      const cplx<T> r = j < M ? mk<T>(tw[j].x, -tw[j].y) : mk<T>(-tw[j - M].x, tw[j - M].y);
+      X = cmul(X, r);
+    }
     const int64_t at = (c * nf + k) * a.nseg + m;
-    Z[at] = X;
-    if (bits) bits[at] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
+    if (Z) Z[at] = X;
+    if (bits) {
+      const T p = X.x * X.x + X.y * X.y;
+      bits[at] = a.real_kind == 0 ? log2_t(sqrt_t(p) + eps) : (a.real_kind == 1 ? sqrt_t(p) : p);
+    }
   }
 }
 
@@ -266,10 +290,13 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
 template <typename T>
 int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
                       int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st,
-                      double* welch_part, int32_t* ngroups_out) {
+                      double* welch_part, const StftSliding* sl) {
   StftFusedArgs a;
   a.welch_part = welch_part;
-  (void)ngroups_out;
+  a.pad_mode = sl ? sl->pad_mode : 0;
+  a.detrend = sl ? sl->detrend : 1;
+  a.real_kind = sl ? sl->real_kind : 0;
+  a.roll = sl ? sl->roll : 0;
   a.n = n;
   a.seg = seg;
   a.hop = hop;
@@ -300,9 +327,9 @@ int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C
 }
 
 template int launch_stft_fused<float>(const float*, const float*, float2*, float*, int64_t, int64_t, int64_t, int64_t,
-                                      int64_t, int64_t, int64_t, double, double, hipStream_t, double*, int32_t*);
+                                      int64_t, int64_t, int64_t, double, double, hipStream_t, double*, const StftSliding*);
 template int launch_stft_fused<double>(const double*, const double*, double2*, double*, int64_t, int64_t, int64_t, int64_t,
-                                       int64_t, int64_t, int64_t, double, double, hipStream_t, double*, int32_t*);
+                                       int64_t, int64_t, int64_t, double, double, hipStream_t, double*, const StftSliding*);
 
 // Welch power spectrum on the fused kernel: partial sums per segment group in `part` ([C][groups][nfft / 2 + 1] doubles,
 // groups <= nseg), then the mean over the segments with scipy's one-sided "spectrum" weights
