@@ -5,12 +5,16 @@
 // A workgroup owns G consecutive segments of one record.  Per segment a wave loads the (zero-extended) samples,
 // removes their mean (float64 sum, fixed order), applies the window and leaves the nfft real values in LDS packed as
 // M = nfft / 2 complex numbers z[m] = v[2m] + i v[2m+1]; the G transforms of M points run in place in LDS (radix-2^2
-// decimation in frequency, twiddles from an LDS table of exp(-2 pi i k / nfft) built once per workgroup, results in
+// decimation in frequency, twiddles from an LDS table of exp(-2 pi i k / nfft) copied from a per-device table, results in
 // bit-reversed order); the real-input spectra X[k], k = 0..M, are untangled from Z[k], Z[M - k] on the way out and
 // written [frequency][time]: the G segments of a bin are consecutive in memory, so every store is a run of G
 // coefficients (G = 16: 128 B).  HBM traffic = the record once (the 50 % overlap is served by the caches) + the
 // panel once (+ the bits panel when asked for): the algorithmic bytes of SURVEY s8(d).  No MFMA: an FFT has no dense
 // contraction.
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "qi_common.hpp"
 #include "qi_device.hpp"
 #include "qi_fft_reg.hpp"
@@ -23,6 +27,11 @@ namespace {
 #define QI_STFT_THREADS 256
 #endif
 constexpr int kStftThreads = QI_STFT_THREADS;
+#ifdef QI_STFT_WAVES  // experiments: waves per SIMD the register budget must allow
+#define QI_STFT_BOUNDS __launch_bounds__(kStftThreads, QI_STFT_WAVES)
+#else
+#define QI_STFT_BOUNDS __launch_bounds__(kStftThreads)
+#endif
 
 template <typename T>
 __device__ __forceinline__ void sincospi_t(T x, T* s, T* c);
@@ -68,18 +77,23 @@ struct StftFusedArgs {
   // 2: |X|^2)
   int32_t pad_mode, detrend, real_kind;
   int64_t roll;
+  int32_t dbg;  // -DQI_STFT_DBG builds: timing ablations (1: no panel stores, 2: no transforms, 4: no record loads, 8: no bits)
 };
 
-// dynamic LDS: data [G][R (C + 1) + 1] complex | twiddles [M] complex (exp(-2 pi i k / (2 M)))
+// dynamic LDS: data [G][R (C + 1) + 1] complex | twiddles [M + 1] complex (exp(-2 pi i k / (2 M)))
 //
 // The M-point transform of a segment is a four-step transform on the R x C matrix z[r][c] = z[c + C r] (rows padded
 // by one element, segments by one more: every access pattern below is free of bank conflicts):
 //   step 1: thread = column c: R-point transform over r in registers, times W_M^(c k1), back to row k1;
 //   step 2: thread = row k1:   C-point transform over c in registers: row k1, column k2 holds Z[k1 + R k2].
-template <typename T, int LOG2R, int LOG2C>
-__global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict__ sig, const T* __restrict__ win,
-                                                            cplx<T>* __restrict__ Z, T* __restrict__ bits,
-                                                            StftFusedArgs a) {
+//
+// PLAIN: the styx_fft product (zero extension, both panels, log2 bits, no slice rotation) with its loops specialised:
+// whole segments come in as aligned pairs, a thread of the store pass keeps its segment and walks the bins with running
+// addresses.  The general form serves Welch and the ShortTimeFFT convention.
+template <typename T, int LOG2R, int LOG2C, bool PLAIN>
+__global__ void QI_STFT_BOUNDS k_stft_fused(const T* __restrict__ sig, const T* __restrict__ win,
+                                                            const cplx<T>* __restrict__ twg, cplx<T>* __restrict__ Z,
+                                                            T* __restrict__ bits, StftFusedArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   constexpr int R = 1 << LOG2R, C = 1 << LOG2C, M = R * C, RS = C + 1, TILE = R * RS + 1;
   const int G = a.G;
@@ -95,45 +109,139 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   const int64_t c = item / a.ngroups, m0 = (item % a.ngroups) * G;
   const T* __restrict__ x = sig + c * a.n;
 
-  for (int k = tid; k < M; k += kStftThreads) {
-    T s, co;
-    sincospi_t<T>((T)k / (T)M, &s, &co);  // exp(-i pi k / M)
-    tw[k] = mk<T>(co, -s);
+  // exp(-i pi k / M), k = 0..M: requested first, left in LDS after the segments (one round trip, not one per sweep)
+  constexpr int NT = (M + kStftThreads) / kStftThreads;
+  cplx<T> twv[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int k = tid + i * kStftThreads;
+    twv[i] = k <= M ? twg[k] : mk<T>(T(0), T(0));
   }
   // segments: one wave per segment (mean by wave shuffles, no workgroup barrier)
-  for (int g = wv; g < G; g += kStftThreads / kWave) {
+  constexpr int NW = kStftThreads / kWave, NP = (M + kWave - 1) / kWave;
+  constexpr bool kFast = NP * sizeof(cplx<T>) <= 128;  // the paths that hold a segment and its window in registers
+  auto one_segment = [=](int g) {
     const int64_t m = m0 + g;
     cplx<T>* __restrict__ d = data + (size_t)g * TILE;
     if (m >= a.nseg) {  // past the last segment: zeros (never stored)
       for (int j = lane; j < M; j += kWave) d[(j >> LOG2C) * RS + (j & (C - 1))] = mk<T>(T(0), T(0));
-      continue;
+      return;
     }
-    // the segment's samples, once, into registers: lane l holds the pairs (2 j, 2 j + 1), j = l + 64 t (two coalesced
-    // loads per pair; out-of-record samples of the zero extension are zeros and count in the mean, as in the reference)
+    // the segment's samples, once, into registers: lane l holds the pairs (2 j, 2 j + 1), j = l + 64 t (out-of-record
+    // samples of the zero extension are zeros and count in the mean, as in the reference)
     const int64_t base = m * a.hop - a.lead;
-    constexpr int NP = (M + kWave - 1) / kWave;
+    const int pad_mode = PLAIN ? 0 : a.pad_mode;
     T v0[NP], v1[NP];
+    // a segment of nfft samples inside the record, 2-sample aligned: one load per pair
+    const bool whole = kFast && a.seg == 2 * M && base >= 0 && base + 2 * M <= a.n &&
+                       ((reinterpret_cast<uintptr_t>(x + base) | reinterpret_cast<uintptr_t>(win)) & (2 * sizeof(T) - 1)) == 0;
+    if (whole) {
+      const cplx<T>* __restrict__ xp = reinterpret_cast<const cplx<T>*>(x + base);
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        const int j = lane + kWave * t;
+        const cplx<T> q = (NP * kWave == M || j < M) ? xp[j] : mk<T>(T(0), T(0));
+        v0[t] = q.x;
+        v1[t] = q.y;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        const int64_t i0 = 2 * (int64_t)(lane + kWave * t), k0 = base + i0;
+        v0[t] = i0 < a.seg ? stft_sample<T>(x, a.n, k0, pad_mode) : T(0);
+        v1[t] = i0 + 1 < a.seg ? stft_sample<T>(x, a.n, k0 + 1, pad_mode) : T(0);
+      }
+    }
     double acc = 0.0;
 #pragma unroll
-    for (int t = 0; t < NP; ++t) {
-      const int64_t i0 = 2 * (int64_t)(lane + kWave * t), k0 = base + i0;
-      v0[t] = i0 < a.seg ? stft_sample<T>(x, a.n, k0, a.pad_mode) : T(0);
-      v1[t] = i0 + 1 < a.seg ? stft_sample<T>(x, a.n, k0 + 1, a.pad_mode) : T(0);
-      acc += (double)v0[t] + (double)v1[t];
-    }
+    for (int t = 0; t < NP; ++t) acc += (double)v0[t] + (double)v1[t];
     acc = wave_sum(acc);
     const T mean = a.detrend ? (T)(acc / (double)a.seg) : T(0);
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       const int j = lane + kWave * t;
-      const int64_t i0 = 2 * (int64_t)j;
-      const T w0 = i0 < a.seg ? win[i0] : T(0), w1 = i0 + 1 < a.seg ? win[i0 + 1] : T(0);
-      if (j < M) d[(j >> LOG2C) * RS + (j & (C - 1))] = mk<T>((v0[t] - mean) * w0, (v1[t] - mean) * w1);
+      if (NP * kWave == M || j < M) {
+        T w0, w1;
+        if (whole) {
+          const cplx<T> w = reinterpret_cast<const cplx<T>*>(win)[j];
+          w0 = w.x;
+          w1 = w.y;
+        } else {
+          const int64_t i0 = 2 * (int64_t)j;
+          w0 = i0 < a.seg ? win[i0] : T(0);
+          w1 = i0 + 1 < a.seg ? win[i0 + 1] : T(0);
+        }
+        d[(j >> LOG2C) * RS + (j & (C - 1))] = mk<T>((v0[t] - mean) * w0, (v1[t] - mean) * w1);
+      }
     }
+  };
+  // Two consecutive segments at half overlap (the product's geometry) share their middle half: a wave loads the three
+  // halves once, all in flight together, and windows them twice.
+#ifdef QI_STFT_NO_PAIRS
+  constexpr bool kPairs = false;
+#else
+  constexpr bool kPairs = PLAIN && NP >= 2 && NP * kWave == M && kFast;
+#endif
+  bool pairs = false;
+  if constexpr (kPairs)
+    pairs = a.hop == M && a.seg == 2 * M && (G & 1) == 0 && (reinterpret_cast<uintptr_t>(win) & (2 * sizeof(T) - 1)) == 0;
+  if (pairs) {
+    if constexpr (kPairs) {
+      constexpr int NH = NP / 2;  // pairs of samples per lane and half segment
+      for (int g = 2 * wv; g < G; g += 2 * NW) {
+        const int64_t m = m0 + g, base = m * a.hop - a.lead;
+        if (!(m + 1 < a.nseg && base >= 0 && base + 3 * M <= a.n &&
+              (reinterpret_cast<uintptr_t>(x + base) & (2 * sizeof(T) - 1)) == 0)) {
+          one_segment(g);
+          one_segment(g + 1);
+          continue;
+        }
+        const cplx<T>* __restrict__ xp = reinterpret_cast<const cplx<T>*>(x + base);
+        const cplx<T>* __restrict__ wp = reinterpret_cast<const cplx<T>*>(win);
+        cplx<T> h[3][NH], w[2][NH];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < NH; ++t) h[q][t] = xp[q * (M / 2) + lane + kWave * t];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NH; ++t) w[q][t] = wp[q * (M / 2) + lane + kWave * t];
+        double sh[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          sh[q] = 0.0;
+#pragma unroll
+          for (int t = 0; t < NH; ++t) sh[q] += (double)h[q][t].x + (double)h[q][t].y;
+        }
+        const double accA = wave_sum(sh[0] + sh[1]), accB = wave_sum(sh[1] + sh[2]);
+        const T meanA = a.detrend ? (T)(accA / (double)a.seg) : T(0), meanB = a.detrend ? (T)(accB / (double)a.seg) : T(0);
+        cplx<T>* __restrict__ dA = data + (size_t)g * TILE;
+        cplx<T>* __restrict__ dB = dA + TILE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int t = 0; t < NH; ++t) {
+            const int j = q * (M / 2) + lane + kWave * t, at = (j >> LOG2C) * RS + (j & (C - 1));
+            dA[at] = mk<T>((h[q][t].x - meanA) * w[q][t].x, (h[q][t].y - meanA) * w[q][t].y);
+            dB[at] = mk<T>((h[q + 1][t].x - meanB) * w[q][t].x, (h[q + 1][t].y - meanB) * w[q][t].y);
+          }
+      }
+    }
+  } else {
+    for (int g = wv; g < G; g += NW) one_segment(g);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int k = tid + i * kStftThreads;
+    if (k <= M) tw[k] = twv[i];
   }
   __syncthreads();
 
   // step 1: columns
+#ifdef QI_STFT_DBG
+  if (!(a.dbg & 2))
+#endif
   for (int q = tid; q < G * C; q += kStftThreads) {
     const int g = q >> LOG2C, cc = q & (C - 1);
     cplx<T>* __restrict__ d = data + (size_t)g * TILE + cc;
@@ -154,6 +262,9 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   }
   __syncthreads();
   // step 2: rows
+#ifdef QI_STFT_DBG
+  if (!(a.dbg & 2))
+#endif
   for (int q = tid; q < G * R; q += kStftThreads) {
     const int g = q >> LOG2R, k1 = q & (R - 1);
     cplx<T>* __restrict__ d = data + (size_t)g * TILE + k1 * RS;
@@ -170,13 +281,54 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
   // Z[k] = row k mod R, column k / R.  Consecutive threads take consecutive segments of one bin.
   const int nf = M + 1, lg = a.log2g;
   const T scale = (T)a.scale, eps = (T)a.eps;
+  if constexpr (PLAIN) {
+    // thread = (bin k0 of a sweep of S = threads / G bins, segment g): its segment, its tile and its place in a row stay;
+    // bins advance by S, the panel addresses by S rows
+    const int g = tid & (G - 1), S = kStftThreads >> lg;
+    const int64_t m = m0 + g;
+    if (m >= a.nseg) return;
+    const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
+    const T hs = T(0.5) * scale;
+    const int64_t row0 = (c * nf + (tid >> lg)) * a.nseg + m, step = (int64_t)S * a.nseg;
+    cplx<T>* __restrict__ zp = Z + row0;
+    T* __restrict__ bp = bits + row0;
+    for (int k = tid >> lg; k < nf; k += S, zp += step, bp += step) {
+      const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+      const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
+      const cplx<T> w = tw[k];  // tw[M] = -1
+      // X = scale (e - i w o), e = (Z[k] + conj Z[M-k]) / 2, o = (Z[k] - conj Z[M-k]) / 2
+      const cplx<T> o = mk<T>(za.x - zb.x, za.y + zb.y);
+      const cplx<T> wo = cmul(o, w);
+      const cplx<T> X = mk<T>(hs * ((za.x + zb.x) + wo.y), hs * ((za.y - zb.y) - wo.x));
+      const T p = X.x * X.x + X.y * X.y;
+#ifdef QI_STFT_DBG
+      if (a.dbg & 1) {
+        const T b = (a.dbg & 8) ? p : log2_t(sqrt_t(p) + eps);
+        if (b == T(12345.678)) *zp = X;
+        continue;
+      }
+      if (a.dbg & 8) {
+        *zp = X;
+        continue;
+      }
+#endif
+#ifdef QI_STFT_NT
+      stream_store(zp, X);
+      __builtin_nontemporal_store(log2_t(sqrt_t(p) + eps), bp);
+#else
+      *zp = X;
+      *bp = log2_t(sqrt_t(p) + eps);
+#endif
+    }
+    return;
+  }
   if (a.welch_part) {
     // Welch mean (styx_fft.py:230-266): the sum over this workgroup's segments of |X[k]|^2, one partial per (record,
     // group, bin); k_welch_reduce adds the groups in index order
     double* __restrict__ part = a.welch_part + ((size_t)c * a.ngroups + (size_t)(item % a.ngroups)) * nf;
     for (int k = tid; k < nf; k += kStftThreads) {
       const int ka = k & (M - 1), kb = (M - k) & (M - 1);
-      const cplx<T> w = k < M ? tw[k] : mk<T>(T(-1), T(0));
+      const cplx<T> w = tw[k];
       double acc = 0.0;
       for (int g = 0; g < G && m0 + g < a.nseg; ++g) {
         const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
@@ -200,8 +352,7 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_fused(const T* __restrict
     const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
     const cplx<T> e = mk<T>(T(0.5) * (za.x + zb.x), T(0.5) * (za.y - zb.y));   // (Z[k] + conj Z[M-k]) / 2
     const cplx<T> o = mk<T>(T(0.5) * (za.x - zb.x), T(0.5) * (za.y + zb.y));   // (Z[k] - conj Z[M-k]) / 2
-    const cplx<T> w = k < M ? tw[k] : mk<T>(T(-1), T(0));
-    const cplx<T> wo = cmul(o, w);
+    const cplx<T> wo = cmul(o, tw[k]);
     cplx<T> X = mk<T>(e.x + wo.y, e.y - wo.x);  // e - i (w o)
     X.x *= scale;
     X.y *= scale;
@@ -248,7 +399,7 @@ static bool stft_shape(int64_t M, int* lr, int* lc) {
 static int stft_fused_group(int64_t M, int lr, int lc, size_t esz, size_t budget) {
   const size_t tile = ((size_t)1 << lr) * (((size_t)1 << lc) + 1) + 1;
   for (int G = 16; G >= 1; G >>= 1)
-    if (((size_t)G * tile + M) * esz <= budget) return G;
+    if (((size_t)G * tile + M + 1) * esz <= budget) return G;
   return 0;
 }
 
@@ -256,6 +407,32 @@ bool stft_fused_supported(int dtype, int64_t seg, int64_t hop, int64_t nfft) {
   int lr, lc;
   if (!(nfft >= 64 && nfft <= 4096 && (nfft & (nfft - 1)) == 0 && seg <= nfft && seg >= 2 && hop >= 1)) return false;
   return dtype == QI_F64 ? stft_shape<double>(nfft / 2, &lr, &lc) : stft_shape<float>(nfft / 2, &lr, &lc);
+}
+
+// exp(-i pi k / M), k = 0..M, per device and transform length (built on the host in long double, kept for the process)
+template <typename T>
+static int stft_twiddles(int64_t M, const cplx<T>** out) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int64_t>, cplx<T>*> tables;
+  int dev = 0;
+  QI_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tables.find({dev, M});
+  if (it == tables.end()) {
+    std::vector<cplx<T>> h((size_t)M + 1);
+    for (int64_t k = 0; k <= M; ++k) {
+      const long double ph = 3.14159265358979323846264338327950288L * (long double)k / (long double)M;
+      h[(size_t)k] = mk<T>((T)cosl(ph), (T)-sinl(ph));
+    }
+    h[(size_t)M] = mk<T>(T(-1), T(0));
+    if (M % 2 == 0) h[(size_t)(M / 2)] = mk<T>(T(0), T(-1));
+    cplx<T>* d = nullptr;
+    QI_HIP(hipMalloc(reinterpret_cast<void**>(&d), h.size() * sizeof(cplx<T>)));
+    QI_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(cplx<T>), hipMemcpyHostToDevice));
+    it = tables.emplace(std::make_pair(dev, M), d).first;
+  }
+  *out = it->second;
+  return QI_OK;
 }
 
 static thread_local int32_t g_last_ngroups = 0;  // segment groups per record of this thread's last launch (Welch partials)
@@ -275,14 +452,23 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
   a.log2g = 0;
   while ((1 << a.log2g) < G) ++a.log2g;
   const size_t tile = ((size_t)1 << LR) * (((size_t)1 << LC) + 1) + 1;
-  const size_t lds = ((size_t)G * tile + M) * sizeof(cplx<T>);
-  QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC>), lds));
+  const size_t lds = ((size_t)G * tile + M + 1) * sizeof(cplx<T>);
+  const cplx<T>* twg = nullptr;
+  QI_TRY(stft_twiddles<T>(M, &twg));
+  // the product's own call (styx_fft: zeros beyond the record, both panels, log2 bits) runs the specialised loops
+  const bool plain = Z && bits && !a.welch_part && a.pad_mode == 0 && a.real_kind == 0 && a.roll == 0;
+  const void* fn = plain ? reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC, true>)
+                         : reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC, false>);
+  QI_TRY(allow_dynamic_lds(fn, lds));
   a.ngroups = (int32_t)ceil_div(nseg, G);
   g_last_ngroups = a.ngroups;
   a.nitems = (int64_t)a.ngroups * C;
   a.per_xcd = (int32_t)ceil_div(a.nitems, 8);
   dim3 grid((unsigned)(8 * a.per_xcd));
-  k_stft_fused<T, LR, LC><<<grid, kStftThreads, lds, st>>>(sig, win, Z, bits, a);
+  if (plain)
+    k_stft_fused<T, LR, LC, true><<<grid, kStftThreads, lds, st>>>(sig, win, twg, Z, bits, a);
+  else
+    k_stft_fused<T, LR, LC, false><<<grid, kStftThreads, lds, st>>>(sig, win, twg, Z, bits, a);
   QI_LAUNCH_CHECK();
   return QI_OK;
 }
@@ -297,6 +483,10 @@ int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C
   a.detrend = sl ? sl->detrend : 1;
   a.real_kind = sl ? sl->real_kind : 0;
   a.roll = sl ? sl->roll : 0;
+  a.dbg = 0;
+#ifdef QI_STFT_DBG
+  if (const char* e = tune_env("QI_STFT_DBG")) a.dbg = atoi(e);
+#endif
   a.n = n;
   a.seg = seg;
   a.hop = hop;
