@@ -85,6 +85,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_LONG")) p->native_blk_long = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_EDGE_MERGE")) p->native_edge_merge = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK_FASTW")) p->native_blk_fastw = atoi(e);
 #ifdef QI_BLK_LZ
   if (const char* e = tune_env("QI_NATIVE_BLK_LZ")) p->native_blk_lz = atoi(e);
@@ -147,6 +148,17 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->blk_stamps) {
     std::vector<unsigned long long> h(65536 * 8);
     if (hipMemcpy(h.data(), p->blk_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (const char* path = tune_env("QI_NATIVE_TIMELINE")) {  // the joint block launch's dispatch timeline (k_block_dual)
+        if (FILE* f = fopen(path, "w")) {
+          fprintf(f, "wg start_10ns end_10ns xcc cu bands wq\n");
+          const unsigned long long m48 = 0xffffffffffffull;
+          for (size_t w = 0; w < 65536; ++w)
+            if (h[w * 8 + 7])
+              fprintf(f, "%zu %llu %llu %llu %llu %llu %lld\n", w, h[w * 8 + 6] & m48, h[w * 8 + 7] & m48, h[w * 8 + 6] >> 56,
+                      (h[w * 8 + 6] >> 48) & 0xff, (h[w * 8 + 7] >> 48) & 0xff, (long long)(signed char)(h[w * 8 + 7] >> 56));
+          fclose(f);
+        }
+      }
       double sum[8] = {0};
       long cnt = 0;
       for (size_t w = 0; w < 65536; ++w) {

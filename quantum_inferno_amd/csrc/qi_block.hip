@@ -276,11 +276,15 @@ __device__ __forceinline__ void block_forward(const T* __restrict__ sig, int64_t
 
 // The bands [band_first, band_first + band_count) of the launch's list on block `blk` of reach group WQ, from the
 // block's spectrum S (natural order; rotated in place here for the Gabor banks).  DEMOD: Stockwell (demodulated outputs).
-template <typename T, int WQ, bool DEMOD, bool COEF, bool BITS>
+// EDGE: the bands are the split bands band_first ... of the styx table (no descriptors: panel rows from a.edge_band, filter
+// spectra from piece `edge_piece` of a.edge_bank), S is the spectrum of that far piece of the record, and the zoom engine's
+// part of every output (a.edge_part) is added before the band is finished (k_block_edge).
+template <typename T, int WQ, bool DEMOD, bool COEF, bool BITS, bool EDGE = false>
 __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i, int32_t band_first, int32_t band_count,
                                             int32_t plane, int32_t stat_slot, cplx<T> (&S)[16], cplx<T>* __restrict__ buf,
                                             const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
-                                            cplx<T> w) {
+                                            cplx<T> w, int edge_piece = 0) {
+  static_assert(!EDGE || !DEMOD, "split bands belong to the styx table");
   constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // the column this thread owns
@@ -292,7 +296,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #endif
   // record samples [t0, t0 + 4096), outputs [t0 + W, t0 + W + V)
   const int64_t t0 = blk * V - W;
-  if (!DEMOD) {
+  if (!DEMOD && !EDGE) {
     // Gabor banks: the half-sample offset of the atoms (styx_cwt.py:113-144) is the factor exp(-i theta_k / 2) of
     // every filter spectrum; it goes into the block spectrum once, which leaves REAL Gaussian weights per band
     const cplx<T> r0 = unit_phasor<T>(-(double)col / (double)kBlk);
@@ -311,13 +315,18 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
   int pending = -1, par = 0;  // band whose wave sums sit in s_red[par ^ 1] until a barrier has passed
 
   // the band descriptor is fetched one band ahead: its load would otherwise sit in front of the filter loads
-  BlockBandT<T> bd_next = a.bands[band_first];
+  BlockBandT<T> bd_next{};
+  if constexpr (!EDGE) bd_next = a.bands[band_first];
   for (int jj = 0; jj < band_count; ++jj) {
-    const BlockBandT<T> bd = bd_next;
-    if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
+    BlockBandT<T> bd = bd_next;
+    if constexpr (EDGE) {
+      bd.out_band = a.edge_band[band_first + jj];
+    } else {
+      if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
+    }
     cplx<T> v[16];
     constexpr bool F64 = sizeof(T) == 8;  // float64 tables hold analytic bands only, none of them `narrow`
-    if (!F64 && bd.narrow == 1) {
+    if (!EDGE && !F64 && bd.narrow == 1) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
       // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
       QI_BSTAMP(1);
@@ -340,7 +349,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
       sparse_head16<T>(v, mk<T>(x.x * r, x.y * r), om);
       if (!QI_BDBG(4)) fft4096_tail<T, 1>(v, buf, tw256, tid, col);
-    } else if (F64 || bd.analytic) {
+    } else if (!EDGE && (F64 || bd.analytic)) {
       // Gaussian filter spectrum in registers: no table traffic (the table rows cost as much L2 bandwidth as the
       // panel costs HBM bandwidth)
       QI_BSTAMP(1);
@@ -403,7 +412,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       }
       }
     } else {
-      const cplx<T>* __restrict__ H = a.bank + (int64_t)bd.bank_row * kBlk + col;
+      const cplx<T>* __restrict__ H =
+          (EDGE ? a.edge_bank + ((int64_t)(band_first + jj) * 2 + edge_piece) * kBlk : a.bank + (int64_t)bd.bank_row * kBlk) + col;
       cplx<T> h[16];
 #pragma unroll
       for (int b = 0; b < 16; ++b) h[b] = QI_BDBG(2) ? S[(b + 1) & 15] : H[256 * b];
@@ -415,7 +425,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    if ((F64 || bd.narrow != 1) && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    if ((EDGE || F64 || bd.narrow != 1) && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
     QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;
@@ -434,6 +444,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
     char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
     char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
+    const cplx<T>* __restrict__ part = EDGE ? a.edge_part + (ch * a.nsplit + band_first + jj) * n : nullptr;
     T rowacc = T(0), pl = T(0);
     // demodulation phasor of output i: ph * r^i (r: 256 samples); every fourth one from the exact power r^4 (at most
     // three roundings), the ones between advance by r -- held one at a time, not as an array of NOUT
@@ -468,6 +479,15 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
         half_swap(z[0].y, z[1].y);
         const uint32_t tt = tp + 256u * (uint32_t)i;  // first sample of this lane's pair
         const bool inside = !GUARD || tt < (uint32_t)n;
+        if constexpr (EDGE) {
+          if (inside) {  // (16 bytes per lane: the pair is adjacent in the zoom engine's row, too)
+            const cplx<T> pa = part[tt], pb = part[tt + 1];
+            z[0].x += pa.x;
+            z[0].y += pa.y;
+            z[1].x += pb.x;
+            z[1].y += pb.y;
+          }
+        }
         T lg[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1113,9 +1133,11 @@ __device__ __forceinline__ void dual_item(const BlockArgs<T>& a0, const BlockArg
 // pieces read the record n/2 - W samples after / before the output block (zero outside the record; a piece whose 4096
 // input samples all lie outside is skipped), their filtered spectra are summed and transformed back once; the zoom
 // engine's part of the band is added and the band is finished like any block band (panel rows, reductions).
+// `follows`: the item's plane and statistics slot already hold the bands before it of a merged item (k_block_edge's blocks
+// with two pieces): added to instead of written.
 template <typename T, int WQ, bool COEF, bool BITS>
 __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
-                                          const cplx<T>* __restrict__ tw256, cplx<T> w) {
+                                          const cplx<T>* __restrict__ tw256, cplx<T> w, bool follows = false) {
   constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
@@ -1171,7 +1193,7 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
     if (COEF && inside) stream_store(coef_row + t, z);
     if (BITS && inside) bits_row[t] = log2_t(sqrt_t(m2) + a.eps);
     const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
-    if (time_row && inside) time_row[t] = p;
+    if (time_row && inside) time_row[t] = follows ? time_row[t] + p : p;
     rowacc += p;
     mx = max_t(mx, p);
     pl += plog2p(p);
@@ -1195,10 +1217,81 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
     if (a.part_band) a.part_band[((int64_t)ch * a.panel_bands + out_band) * a.nblk + blk] = s1;
     if (a.part_stat) {
       double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + it.stat_slot) * 3;
-      o[0] = m;
-      o[1] = s1;
-      o[2] = s2;
+      o[0] = follows ? (o[0] > m ? o[0] : m) : m;
+      o[1] = follows ? o[1] + s1 : s1;
+      o[2] = follows ? o[2] + s2 : s2;
     }
+  }
+}
+
+// The same for ALL split bands of an output block (it.band_first ... + it.band_count): the block's far piece is read and
+// transformed once and the bands run through block_bands (EDGE) like the bands of any item -- one filter multiply, inverse
+// transform and pair epilogue each, one per-time plane and one statistics slot for all of them.  The two blocks around the
+// middle of the record, which see both pieces, go band by band through edge_item.  A kernel of its own (k_block_edge):
+// inside k_block / k_block_dual the band loop costs every variant its register budget (0 -> 236-396 bytes of scratch per
+// lane, measured).
+template <typename T, int WQ, bool COEF, bool BITS>
+__device__ __forceinline__ void edge_block_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
+                                                const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
+                                                cplx<T> w) {
+  constexpr int W = 256 * WQ, V = kBlk - 2 * W;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
+  const int64_t n = a.n, t0 = (int64_t)it.block * V - W;
+  const int64_t in_p[2] = {t0 + (n / 2 - W), t0 - (n / 2 - W)};
+  const bool has_p[2] = {!(in_p[0] >= n || in_p[0] + kBlk <= 0), !(in_p[1] >= n || in_p[1] + kBlk <= 0)};
+  if (has_p[0] && has_p[1]) {  // (the same for every thread of the workgroup)
+    for (int32_t q = 0; q < it.band_count; ++q) {
+      const BlockItem one{it.wq, it.block, it.band_first + q, 0, it.plane, it.stat_slot};
+      if (q > 0) __syncthreads();  // the previous band's statistics have left the exchange buffer
+      edge_item<T, WQ, COEF, BITS>(a, one, buf, tw256, w, q > 0);
+    }
+    return;
+  }
+  const int piece = has_p[0] ? 0 : 1;
+  const T* __restrict__ sig = a.sig + (int64_t)blockIdx.z * n;
+  cplx<T> S[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int64_t t = in_p[piece] + col + 256 * b;
+    S[b] = mk<T>((t >= 0 && t < n) ? sig[t] : T(0), T(0));
+  }
+  fft4096<T, -1>(S, buf, tw256, w, tid, col);
+  cplx<T> Sn[16];  // block_bands' order of the block spectrum
+#pragma unroll
+  for (int b = 0; b < 16; ++b) Sn[b] = S[brev(b, 4)];
+  block_bands<T, WQ, false, COEF, BITS, true>(a, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, Sn, buf, tw256,
+                                              s_red, w, piece);
+}
+
+#ifndef QI_BLK_EDGE_WAVES
+#define QI_BLK_EDGE_WAVES QI_BLK_WAVES
+#endif
+// merged edge items (plan tables for many records): items of the band launch's list (`items`) or of the joint list (`dual`)
+template <typename T, bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, QI_BLK_EDGE_WAVES) k_block_edge(BlockArgs<T> a, const BlockItem* __restrict__ items,
+                                                                              const DualItem* __restrict__ dual) {
+  __shared__ cplx<T> buf[kBlkBuf];
+  __shared__ cplx<T> tw256[256];
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  float sn, cs;
+  sincospif((float)tid * (2.0f / 256.0f), &sn, &cs);
+  tw256[tid] = mk<T>((T)cs, (T)sn);
+  sincospif((float)col * (2.0f / 4096.0f), &sn, &cs);
+  const cplx<T> w = mk<T>((T)cs, (T)sn);
+  BlockItem it;
+  if (items) {
+    it = items[blockIdx.x];
+  } else {
+    const DualItem d = dual[blockIdx.x];
+    it = BlockItem{d.wq, d.block, d.first0, d.count0, d.plane0, d.slot0};
+  }
+  switch (-it.wq) {
+    case 1: edge_block_item<T, 1, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    case 2: edge_block_item<T, 2, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    default: edge_block_item<T, 4, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
   }
 }
 
@@ -1340,6 +1433,9 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
     w = mk<T>((T)c, (T)s);
   }
   const DualItem it = items[blockIdx.x];
+#ifdef QI_NATIVE_STAMPS
+  const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz) the launch's dispatch timeline
+#endif
   if (it.wq < 0) {
     const BlockItem e{it.wq, it.block, it.first0, it.count0, it.plane0, it.slot0};
     switch (-it.wq) {
@@ -1347,17 +1443,31 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
       case 2: edge_item<T, 2, COEF, BITS>(a0, e, buf, tw256, w); break;
       default: edge_item<T, 4, COEF, BITS>(a0, e, buf, tw256, w); break;
     }
-    return;
-  }
-  switch (it.wq) {
-    case 1: dual_item<T, 1, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
-    case 2: dual_item<T, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+  } else {
+    switch (it.wq) {
+      case 1: dual_item<T, 1, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+      case 2: dual_item<T, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
 #ifdef QI_BLK_LZ
-    case kBlkLzA: lz_dual_item<T, 2, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
-    case kBlkLzB: lz_dual_item<T, 4, 3, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
+      case kBlkLzA: lz_dual_item<T, 2, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
+      case kBlkLzB: lz_dual_item<T, 4, 3, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
 #endif
-    default: dual_item<T, 4, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+      default: dual_item<T, 4, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
+    }
   }
+#ifdef QI_NATIVE_STAMPS
+  if (a0.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    unsigned long long* o = a0.stamps + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // (48 bits of time; above them the XCD and the CU's place in it, the item's reach code and band count)
+    o[6] = (wall0 & 0xffffffffffffull) | ((unsigned long long)(xcc & 15) << 56) | ((unsigned long long)((hw >> 8) & 0xff) << 48);
+    o[7] = (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull) | ((unsigned long long)(it.wq & 0xff) << 56) |
+           ((unsigned long long)((it.count0 + it.count2) & 0xff) << 48);
+  }
+#endif
 }
 
 // Coarse stage of the zoom engine (qi_zoom.hip): workgroup (tau1, band, record) transforms the 4096 folded and
@@ -1598,6 +1708,20 @@ static int launch_block_long_dual(const BlockArgs<float>& a0, const BlockArgs<fl
   return QI_OK;
 }
 
+// the merged edge items of a table built for many records: their own launch behind the band items
+static int launch_block_edge(const BlockArgs<float>& a, const BlockItem* items, const DualItem* dual, int32_t count,
+                             int64_t n_channels, hipStream_t st) {
+  if (count <= 0) return QI_OK;
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+  dim3 grid((unsigned)count, 1, (unsigned)n_channels);
+  if (coef && bits) k_block_edge<float, true, true><<<grid, kBlkThreads, 0, st>>>(a, items, dual);
+  else if (coef) k_block_edge<float, true, false><<<grid, kBlkThreads, 0, st>>>(a, items, dual);
+  else if (bits) k_block_edge<float, false, true><<<grid, kBlkThreads, 0, st>>>(a, items, dual);
+  else k_block_edge<float, false, false><<<grid, kBlkThreads, 0, st>>>(a, items, dual);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
 template <>
 int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st) {
   if (a.nitems + a.nedge_items <= 0) return QI_OK;
@@ -1606,9 +1730,13 @@ int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels
   rest.items += a.nlong;
   rest.nitems -= a.nlong;
   rest.nlong = 0;
-  if (rest.nitems + rest.nedge_items <= 0) return QI_OK;
-  dim3 grid((unsigned)(rest.nitems + rest.nedge_items), 1, (unsigned)n_channels);
-  return demod ? launch_block_v<float, true>(rest, grid, st) : launch_block_v<float, false>(rest, grid, st);
+  const int32_t riding = a.edge_merged ? 0 : rest.nedge_items;  // single-band edge items ride at the end of the band launch
+  if (rest.nitems + riding > 0) {
+    dim3 grid((unsigned)(rest.nitems + riding), 1, (unsigned)n_channels);
+    QI_TRY((demod ? launch_block_v<float, true>(rest, grid, st) : launch_block_v<float, false>(rest, grid, st)));
+  }
+  if (a.edge_merged) QI_TRY(launch_block_edge(a, rest.items + rest.nitems, nullptr, a.nedge_items, n_channels, st));
+  return QI_OK;
 }
 
 template <bool DEMOD>
@@ -1640,7 +1768,7 @@ int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channe
 
 template <>
 int launch_block_dual<float>(const BlockArgs<float>& a0, const BlockArgs<float>& a2, const DualItem* items, int32_t nitems,
-                             int32_t nlong, int64_t n_channels, hipStream_t st) {
+                             int32_t nlong, int32_t n_edge, int64_t n_channels, hipStream_t st) {
   if (nitems <= 0) return QI_OK;
   const bool coef = a0.coef != nullptr, bits = a0.bits != nullptr;
   if (coef != (a2.coef != nullptr) || bits != (a2.bits != nullptr) || a0.n != a2.n) {
@@ -1651,13 +1779,17 @@ int launch_block_dual<float>(const BlockArgs<float>& a0, const BlockArgs<float>&
   items += nlong;
   nitems -= nlong;
   if (nitems <= 0) return QI_OK;
-  dim3 grid((unsigned)nitems, 1, (unsigned)n_channels);
-  if (coef && bits) k_block_dual<float, true, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
-  else if (coef) k_block_dual<float, true, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
-  else if (bits) k_block_dual<float, false, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
-  else k_block_dual<float, false, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
-  QI_LAUNCH_CHECK();
-  return QI_OK;
+  // merged edge items (the last n_edge of the list): a launch of their own
+  const int32_t own = a0.edge_merged ? (n_edge < nitems ? n_edge : nitems) : 0;
+  if (nitems - own > 0) {
+    dim3 grid((unsigned)(nitems - own), 1, (unsigned)n_channels);
+    if (coef && bits) k_block_dual<float, true, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+    else if (coef) k_block_dual<float, true, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+    else if (bits) k_block_dual<float, false, true><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+    else k_block_dual<float, false, false><<<grid, kBlkThreads, 0, st>>>(a0, a2, items);
+    QI_LAUNCH_CHECK();
+  }
+  return launch_block_edge(a0, nullptr, items + (nitems - own), own, n_channels, st);
 }
 
 template <>

@@ -278,6 +278,7 @@ struct qi_plan {
       int32_t nitems = 0, nplanes = 0;
       int32_t nlong = 0;        // long-block items, at the front of the list
       int32_t nedge_items = 0;  // edge pieces of the split bands, appended to the item list (styx bank)
+      bool edge_merged = false;  // one edge item per block for all split bands (k_block_edge) instead of one per band and block
       std::vector<native::BlockItem> h_items;  // host copy of d_items (the joint launch list is made from it)
     } var[2];
     int64_t max_blocks = 0;  // partial slots a band row needs
@@ -350,6 +351,7 @@ struct qi_plan {
   // ^ local zoom, an experiment that needs a -DQI_BLK_LZ build (bit 0: the 512-sample reach group, bit 1: the 1024-sample group): block bands of the 512- / 1024-sample reach groups with <= 256 / 128 - 16 spectrum bins from coarse samples + interpolation (qi_block.hip, lz_bands)
   float* d_lz_w = nullptr;     // [2][8][kBlkLzTaps] interpolation weights of the local zoom
   int native_blk_fastw = 1;    // Gaussian weights without wrap-around logic where no alias of the filter spectrum matters
+  int native_edge_merge = 1;   // tables for many records (cut 1): the split bands of a block share one edge item and its forward transforms
   int native_blk_long = 1;     // narrow Gaussian bands of the 1024-sample reach group in 8192-sample blocks (75 % of the outputs kept instead of 50 %)
   int native_blk_half = 1;     // block bands whose filter spectrum lies in the lower half of the block spectrum: eight weights, pruned first pass
   int native_tail = 1;         // time reduction and finalisation of the reductions in one launch

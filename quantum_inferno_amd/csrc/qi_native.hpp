@@ -151,6 +151,7 @@ struct BlockArgs {
   int64_t n;
   int32_t nitems, panel_bands;
   int32_t nedge_items, nsplit;  // edge items of the split bands, after the nitems band items
+  int32_t edge_merged;          // the edge items cover all split bands of a block each and run as a launch of their own
   int32_t nlong;                // of the nitems band items, the first nlong are long-block items (a launch of their own)
   const int32_t* edge_band;     // [nsplit] device: panel row of each split band
   const cplx<T>* edge_bank;     // [nsplit][2][kBlk]
@@ -177,8 +178,9 @@ template <typename T>
 int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st);
 // a0: styx table, a2: Stockwell table; both must agree on which panels (coefficients, bits) are stored
 template <typename T>
+// (n_edge: how many of the list's last items are edge items of the split bands)
 int launch_block_dual(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem* items, int32_t nitems, int32_t nlong,
-                      int64_t n_channels, hipStream_t st);
+                      int32_t n_edge, int64_t n_channels, hipStream_t st);
 int launch_block_taps_gabor(double2* g, int w, const double* d_par, int nb_total, const int32_t* d_ids, int count,
                             hipStream_t st);
 int launch_block_taps_stx(double2* g, int w, const double2* om, int64_t n, int64_t idx, hipStream_t st);

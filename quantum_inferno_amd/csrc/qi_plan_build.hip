@@ -468,11 +468,19 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     if (kind == 0 && p->nsplit > 0) {
       // the edge items of the split bands ride at the end of the launch (light items: they fill its tail); each split
       // band has a per-time plane and one partial slot per block like the other bands of the launch
+      // -- in the table for many records one item per block covers all of them (one plane, one launch of its own)
       const int wq = (int)(p->native_split_e / 512);
-      for (int32_t sb = 0; sb < p->nsplit; ++sb) {
+      il.edge_merged = v == 1 && p->native_edge_merge != 0;
+      if (il.edge_merged) {
         for (int64_t b = 0; b < split_blocks; ++b)
-          items.push_back({-wq, (int32_t)b, sb, 0, il.nplanes, (int32_t)items.size()});
+          items.push_back({-wq, (int32_t)b, 0, p->nsplit, il.nplanes, (int32_t)items.size()});
         il.nplanes += 1;
+      } else {
+        for (int32_t sb = 0; sb < p->nsplit; ++sb) {
+          for (int64_t b = 0; b < split_blocks; ++b)
+            items.push_back({-wq, (int32_t)b, sb, 0, il.nplanes, (int32_t)items.size()});
+          il.nplanes += 1;
+        }
       }
       il.nedge_items = (int32_t)items.size() - il.nitems;
     }

@@ -471,6 +471,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.nitems = il.nitems;
       b.nlong = il.nlong;
       b.nedge_items = il.nedge_items;
+      b.edge_merged = il.edge_merged ? 1 : 0;
       b.nsplit = nsplit;
       b.edge_band = p->d_split_bands;
       b.edge_bank = static_cast<const cplx<T>*>(p->split_bank);
@@ -515,7 +516,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
           count = n_edge;
           nlong = 0;
         }
-        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, nlong, ct, bs));
+        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, nlong, phase == 1 ? 0 : n_edge, ct, bs));
       } else {
         if (finishing) QI_TRY(native::launch_block<T>(finish->blk, finish->demod, finish->ct, bs));
         QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
