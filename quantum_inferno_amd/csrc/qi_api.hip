@@ -104,7 +104,14 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     const int short64 = p->native_short && !(tune_env("QI_NATIVE_SHORT64") && atoi(tune_env("QI_NATIVE_SHORT64")) == 0);
     // (the block engine runs float64 tables in double arithmetic: analytic Gaussian bands, no narrow-spectrum shortcuts)
     const int block64 = p->native_block && !(tune_env("QI_NATIVE_BLOCK64") && atoi(tune_env("QI_NATIVE_BLOCK64")) == 0);
-    p->native_zoom = p->native_split = 0;
+    // (split bands: tapered part on the float64 zoom, edge pieces on the float64 block engine)
+    const int split64 = p->native_split && block64 && p->native_z64 &&
+                        !(tune_env("QI_NATIVE_SPLIT64") && atoi(tune_env("QI_NATIVE_SPLIT64")) == 0);
+    p->native_zoom = 0;
+    p->native_split = split64;
+    // (a longer taper than the float32 engines': the tapered spectrum is half as wide at the 2^-50 level the float64 zoom
+    // keeps -- a coarser grid for every split band; measured 10.03 against 10.29 ms at order 12 x 4 records)
+    if (!tune_env("QI_NATIVE_SPLIT_E")) p->native_split_e = 2048;
     p->native_block = block64;
     p->native_short = short64;  // wide-spectrum, short-atom styx bands as circular correlations of length n + edge fix
     p->native_rows = 8;

@@ -1372,6 +1372,28 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a)
   }
 }
 
+// the split bands of a float64 styx table: one edge item per block (edge_block_item), always a launch of its own
+template <bool COEF, bool BITS>
+__global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<double> a, const BlockItem* __restrict__ items) {
+  extern __shared__ __attribute__((aligned(16))) char smem64[];
+  double2* buf = reinterpret_cast<double2*>(smem64);
+  double2* tw256 = buf + kBlkBuf;
+  __shared__ double s_red[2][kBlkThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
+  double s, c;
+  sincospi((double)tid * (2.0 / 256.0), &s, &c);
+  tw256[tid] = make_double2(c, s);
+  sincospi((double)col * (2.0 / 4096.0), &s, &c);
+  const double2 w = make_double2(c, s);
+  const BlockItem it = items[blockIdx.x];
+  switch (-it.wq) {
+    case 1: edge_block_item<double, 1, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    case 2: edge_block_item<double, 2, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    default: edge_block_item<double, 4, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+  }
+}
+
 // long-block items (BlockItem::wq = kBlkLongWq) have kernels of their own: their register budget (the even samples of a
 // band are held while its odd samples are transformed) would spill inside k_block / k_block_dual
 template <typename T, bool DEMOD, bool COEF, bool BITS>
@@ -1757,13 +1779,32 @@ static int launch_block64_v(const BlockArgs<double>& a, dim3 grid, hipStream_t s
 }
 template <>
 int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channels, hipStream_t st) {
-  if (a.nitems <= 0) return QI_OK;
-  if (a.nlong > 0 || a.nedge_items > 0) {
-    set_error("block engine: float64 tables have neither long blocks nor split bands");
+  if (a.nitems + a.nedge_items <= 0) return QI_OK;
+  if (a.nlong > 0 || (a.nedge_items > 0 && !a.edge_merged)) {
+    set_error("block engine: float64 tables have no long blocks, and their split bands one edge item per block");
     return QI_ERR_STATE;
   }
-  dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
-  return demod ? launch_block64_v<true>(a, grid, st) : launch_block64_v<false>(a, grid, st);
+  if (a.nitems > 0) {
+    dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
+    QI_TRY((demod ? launch_block64_v<true>(a, grid, st) : launch_block64_v<false>(a, grid, st)));
+  }
+  if (a.nedge_items > 0) {
+    const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+    dim3 grid((unsigned)a.nedge_items, 1, (unsigned)n_channels);
+    const BlockItem* items = a.items + a.nitems;
+#define QI_E64(C, B)                                                                                 \
+  do {                                                                                               \
+    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_block64_edge<C, B>), kBlk64Lds));      \
+    k_block64_edge<C, B><<<grid, kBlkThreads, kBlk64Lds, st>>>(a, items);                            \
+  } while (0)
+    if (coef && bits) QI_E64(true, true);
+    else if (coef) QI_E64(true, false);
+    else if (bits) QI_E64(false, true);
+    else QI_E64(false, false);
+#undef QI_E64
+    QI_LAUNCH_CHECK();
+  }
+  return QI_OK;
 }
 
 template <>

@@ -288,6 +288,8 @@ struct Z64Args {
   float two_over_len;
   cplx<double>* coef;           // [C][panel_bands][n] or null
   double* bits;
+  cplx<double>* split_part;     // [C][split_rows][n]: the split bands (BandDesc::add_row) leave their samples here, see k_z64_interp
+  int32_t split_rows;
   double* time_part;            // [C][chunk_total][n] per-time planes (or the output row itself when chunk_total = 1)
   double* part_band;            // [C][panel_bands][nblk]
   double* part_stat;            // [C][stat_stride][3]

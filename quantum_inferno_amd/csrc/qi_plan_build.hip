@@ -470,7 +470,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       // band has a per-time plane and one partial slot per block like the other bands of the launch
       // -- in the table for many records one item per block covers all of them (one plane, one launch of its own)
       const int wq = (int)(p->native_split_e / 512);
-      il.edge_merged = v == 1 && p->native_edge_merge != 0;
+      il.edge_merged = (v == 1 && p->native_edge_merge != 0) || F64;  // (float64: always, k_block64_edge)
       if (il.edge_merged) {
         for (int64_t b = 0; b < split_blocks; ++b)
           items.push_back({-wq, (int32_t)b, 0, p->nsplit, il.nplanes, (int32_t)items.size()});
@@ -695,11 +695,19 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
   const int64_t se = p->native_split_e;
   if (bank == QI_BANK_STYX && p->native_split && can_block && !picks.empty() &&  // (their edge items ride in the block launch)
       (se == 512 || se == 1024 || se == 2048) && n >= 8 * se) {
+    // float64: "the zoom engine" is the float64 zoom, which takes a band whose support its finest grid oversamples four times
+    const bool z64 = p->d.dtype == QI_F64;
+    auto z64_takes = [&](int64_t len) {
+      return z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L) &&
+             4 * len <= ((L / 64) << (p->native_z64_levels - 1));
+    };
     for (int32_t j : keep) {
       const int64_t lo = (int64_t)sup[3 * j + 1], hi = (int64_t)sup[3 * j + 2];
       const int64_t len = hi >= lo ? hi - lo + 1 : 0;
       // (a band the one-pass loader of the two-pass kernels would take stays there only where those kernels exist)
-      if (zoom_class(p, bank, L, len) >= 0 || (len > 0 && len <= p->native_kmax && native_len_ok(L))) continue;
+      if (z64 ? z64_takes(len)
+              : (zoom_class(p, bank, L, len) >= 0 || (len > 0 && len <= p->native_kmax && native_len_ok(L))))
+        continue;
       std::vector<double> part;
       QI_TRY(analyse_support(p, 0, L, B, j, 1, d_par, &part, st, (double)se));
       const int64_t tlo = (int64_t)part[1], thi = (int64_t)part[2];
@@ -707,7 +715,7 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
       if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] band %d: support %lld bins as the reference cuts it, %lld bins tapered over %lld samples\n",
                 j, (long long)len, (long long)tlen, (long long)se);
-      if (zoom_class(p, bank, L, tlen) < 0) continue;
+      if (z64 ? !z64_takes(tlen) : zoom_class(p, bank, L, tlen) < 0) continue;
       std::copy(part.begin(), part.end(), sup.begin() + 3 * j);
       split.push_back(j);
     }

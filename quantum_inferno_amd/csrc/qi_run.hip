@@ -840,8 +840,9 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   int64_t blk_stats = 0;
   if (blocks) {
     chunk_total += il.nplanes;
-    blk_stats = il.nitems;
+    blk_stats = il.nitems + il.nedge_items;
   }
+  const int32_t nsplit = kind == 0 && blocks ? p->nsplit : 0;  // split bands: the zoom launches hand their part to the edge items
   // stat slots: [chunks of the two-pass and zoom launches][nblk], then one per block item, then the edge bands
   const int64_t blk_stat_base = (int64_t)chunk_blk * nblk;
   const int64_t stat_slots = blk_stat_base + blk_stats + (shorts ? p->nedge : 0);
@@ -860,7 +861,8 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   const size_t e_ep = shorts ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_et = shorts ? (size_t)2 * p->edge_wmax * sizeof(T) : 0;
   const size_t e_ez = shorts && !out->coef ? (size_t)p->nedge * 2 * p->edge_wmax * sizeof(cplx<T>) : 0;
-  const size_t per_chan = e_x + e_xn + e_imd + e_z + e_pb + e_ps + e_tp + e_ep + e_et + e_ez;
+  const size_t e_add = (size_t)nsplit * n * sizeof(cplx<T>);
+  const size_t per_chan = e_x + e_xn + e_imd + e_z + e_pb + e_ps + e_tp + e_ep + e_et + e_ez + e_add;
   if (p->ws_bytes < per_chan + 16384) {
     set_error("workspace of %zu bytes cannot hold one record's float64 scratch of %zu bytes", p->ws_bytes, per_chan + 16384);
     return QI_ERR_NOMEM;
@@ -878,6 +880,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   cplx<T>* Xn = reinterpret_cast<cplx<T>*>(carve(e_xn));
   cplx<T>* imd = reinterpret_cast<cplx<T>*>(carve(e_imd));
   cplx<T>* Z = reinterpret_cast<cplx<T>*>(carve(e_z));
+  cplx<T>* zadd = e_add ? reinterpret_cast<cplx<T>*>(carve(e_add)) : nullptr;
   char* parts0 = w;  // the partial sums: cleared per tile when the sub-tables fill different numbers of slots
   double* part_band = reinterpret_cast<double*>(carve(e_pb));
   double* part_stat = reinterpret_cast<double*>(carve(e_ps));
@@ -968,6 +971,8 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.two_over_len = (float)(2.0 / (double)Lf);
       z.coef = coef;
       z.bits = bits;
+      z.split_part = zadd;
+      z.split_rows = nsplit;
       z.time_part = tpart;
       z.part_band = want_band ? part_band : nullptr;
       z.part_stat = want_stat ? part_stat : nullptr;
@@ -992,6 +997,12 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       native::BlockArgs<T> b{};
       b.n = n;
       b.nitems = il.nitems;
+      b.nedge_items = nsplit > 0 ? il.nedge_items : 0;
+      b.edge_merged = il.edge_merged ? 1 : 0;
+      b.nsplit = nsplit;
+      b.edge_band = p->d_split_bands;
+      b.edge_bank = static_cast<const cplx<T>*>(p->split_bank);
+      b.edge_part = zadd;
       b.panel_bands = (int32_t)B;
       b.items = il.d_items;
       b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);

@@ -115,8 +115,13 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       st = mk<double>(c, s);
     }
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
-    cd* __restrict__ coef_row = a.coef ? a.coef + orow : nullptr;
-    double* __restrict__ bits_row = a.bits ? a.bits + orow : nullptr;
+    // split band (bd.add_row): this is only the tapered part of its atom -- the samples go to row add_row - 1 of
+    // split_part and count for nothing here; the edge items of the block launch add their part and finish the band
+    const bool part = bd.add_row != 0;
+    cd* __restrict__ coef_row =
+        part ? a.split_part + ((int64_t)ch * a.split_rows + (bd.add_row - 1)) * n : (a.coef ? a.coef + orow : nullptr);
+    double* __restrict__ bits_row = a.bits && !part ? a.bits + orow : nullptr;
+    const double pscale = part ? 0.0 : a.power_scale;
     double rowacc = 0.0, pl = 0.0;
     __syncthreads();
 #pragma unroll 2
@@ -138,14 +143,14 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       if (coef_row) stream_store(coef_row + tt, z);
       const double m2 = norm2(z.x, z.y);
       if (bits_row) bits_row[tt] = log2_t(sqrt_t(m2) + a.eps);
-      const double p = mul_rn(a.power_scale, m2);
+      const double p = mul_rn(pscale, m2);
       col0[r * kZ64Threads] += p;
       rowacc += p;
       mx = max_t(mx, p);
       pl += plog2p(p, ltab);
     }
     plogp += pl;
-    if (a.part_band) {
+    if (a.part_band && !part) {  // (the same for every thread)
       const double rs = wave_sum(rowacc);
       if (lane == 0) s_red[wv] = rs;
       __syncthreads();
