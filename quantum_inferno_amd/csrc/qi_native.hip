@@ -321,15 +321,27 @@ __global__ void __launch_bounds__(C::TH) k_pass1(RowArgs<T> a) {
   cplx<T>* tw = buf + C::BUF;
   const int tid = threadIdx.x;
   const int64_t ch = blockIdx.z;
-  const uint32_t row0 = blockIdx.x * C::G;
-  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;  // lanes run over the G rows
-  fill_step_twiddles<T, C>(tw);
   // with phase_split the decimation-in-frequency phases of a 2048-point pass are separate workgroups (blockIdx.y =
   // band * NPH + phase): twice the workgroups for launches that would not cover the chip
   const int split = (NPH > 1 && a.phase_split) ? NPH : 1;
-  const int ph_first = split > 1 ? (int)(blockIdx.y % NPH) : 0, ph_last = split > 1 ? ph_first + 1 : NPH;
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (SRC == 2 && gridDim.y == 1 && (gridDim.x & 7) == 0) {
+    bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);  // (one workgroup per row group: see below)
+  } else if (SRC == 2 && NPH == 2 && split == 2 && gridDim.y == 2 && (gridDim.x & 7) == 0) {
+    // forward transform of real records: a row group reads G floats (64 bytes at G = 16) of every 4 KB of the record, and
+    // both phases read the same ones.  Consecutive workgroups go to consecutive XCDs (eight L2s): every XCD takes a
+    // contiguous range of row groups, the two phases of a group back to back, so that the other half of a 128-byte line
+    // and the second phase's reads are served by the same L2 (4.0 x the record's bytes were fetched before)
+    const uint32_t lin = bx + gridDim.x * by, per = gridDim.x >> 3;
+    bx = (lin & 7u) * per + ((lin >> 3) >> 1);
+    by = (lin >> 3) & 1u;
+  }
+  const uint32_t row0 = bx * C::G;
+  const int d2 = tid / (4 * C::G), c2 = (tid % (4 * C::G)) / C::G, g2 = tid % C::G;  // lanes run over the G rows
+  fill_step_twiddles<T, C>(tw);
+  const int ph_first = split > 1 ? (int)(by % NPH) : 0, ph_last = split > 1 ? ph_first + 1 : NPH;
   BandDesc bd{};
-  if constexpr (SRC != 2) bd = a.bands[a.gen_list[blockIdx.y / split]];
+  if constexpr (SRC != 2) bd = a.bands[a.gen_list[by / split]];
   const cplx<T>* Xc = SRC == 2 ? nullptr : a.X + ch * a.Lf;
   const T* sigc = SRC == 2 ? a.sig + ch * a.n : nullptr;
   const uint32_t mask = (uint32_t)a.Lf - 1u;
