@@ -1553,8 +1553,17 @@ template <typename T, int NF>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse2g(ZoomArgs<T> a0, ZoomArgs<T> a2) {
   __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
-  if (blockIdx.x < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false, NF>(a0, blockIdx.x, buf, tw256);
-  else zoom_coarse_plane_gather<T, true, NF>(a2, blockIdx.x - (uint32_t)a0.planes, buf, tw256);
+  // Consecutive workgroups go to consecutive XCDs; the planes of a band (>= 4 or 8 consecutive plane indices) all gather the
+  // same bins of the spectrum and the same filter row: runs of eight consecutive planes stay behind one L2, the runs take
+  // turns over the XCDs (the grid is rounded up to a multiple of 64).
+#ifdef QI_COARSE_PLAIN_ORDER
+  const uint32_t pi = blockIdx.x;
+#else
+  const uint32_t q = blockIdx.x >> 3, pi = (q >> 3) * 64u + (blockIdx.x & 7u) * 8u + (q & 7u);
+#endif
+  if (pi >= (uint32_t)(a0.planes + a2.planes)) return;
+  if (pi < (uint32_t)a0.planes) zoom_coarse_plane_gather<T, false, NF>(a0, pi, buf, tw256);
+  else zoom_coarse_plane_gather<T, true, NF>(a2, pi - (uint32_t)a0.planes, buf, tw256);
 }
 template <typename T, bool STX>
 __global__ void __launch_bounds__(kBlkThreads) k_zoom_coarse_g(ZoomArgs<T> a) {
@@ -1860,7 +1869,7 @@ int launch_zoom_coarse_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<
     set_error("zoom engine: the joint coarse stage takes a styx table and a Stockwell table");
     return QI_ERR_STATE;
   }
-  dim3 grid((unsigned)(a0.planes + a2.planes), 1, (unsigned)n_channels);
+  dim3 grid((unsigned)(((a0.planes + a2.planes) + 63) / 64 * 64), 1, (unsigned)n_channels);
   // few records: a couple of workgroups per CU, each waiting on its loads -- twice as many in flight
   static const int nf_forced = tune_env("QI_NATIVE_COARSE_NF") ? atoi(tune_env("QI_NATIVE_COARSE_NF")) : 0;
   if (nf_forced == 8 || (nf_forced != 16 && n_channels > 2)) k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
