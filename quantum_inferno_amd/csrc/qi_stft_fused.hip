@@ -292,33 +292,37 @@ __global__ void QI_STFT_BOUNDS k_stft_fused(const T* __restrict__ sig, const T* 
     const int64_t row0 = (c * nf + (tid >> lg)) * a.nseg + m, step = (int64_t)S * a.nseg;
     cplx<T>* __restrict__ zp = Z + row0;
     T* __restrict__ bp = bits + row0;
-    for (int k = tid >> lg; k < nf; k += S, zp += step, bp += step) {
-      const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+    // the bins k and M - k together: one pair of reads, one product (exp(-i pi (M - k) / M) = -conj exp(-i pi k / M)) and
+    // the sums shared -- X[M - k] = scale ((e.x - (w o).y), -(e.y) - (w o).x) in the terms of X[k]; two row streams, one up,
+    // one down (0.395 -> 0.38 ms at configs[2])
+    cplx<T>* __restrict__ zq = Z + (c * nf + (M - (tid >> lg))) * a.nseg + m;
+    T* __restrict__ bq = bits + (c * nf + (M - (tid >> lg))) * a.nseg + m;
+    for (int k = tid >> lg; k <= M / 2; k += S, zp += step, bp += step, zq -= step, bq -= step) {
+      const int ka = k, kb = (M - k) & (M - 1);
       const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
-      const cplx<T> w = tw[k];  // tw[M] = -1
-      // X = scale (e - i w o), e = (Z[k] + conj Z[M-k]) / 2, o = (Z[k] - conj Z[M-k]) / 2
-      const cplx<T> o = mk<T>(za.x - zb.x, za.y + zb.y);
-      const cplx<T> wo = cmul(o, w);
-      const cplx<T> X = mk<T>(hs * ((za.x + zb.x) + wo.y), hs * ((za.y - zb.y) - wo.x));
-      const T p = X.x * X.x + X.y * X.y;
+      const cplx<T> w = tw[k];
+      const T A = za.x + zb.x, B = za.y - zb.y;
+      const cplx<T> wo = cmul(mk<T>(za.x - zb.x, za.y + zb.y), w);
+      const cplx<T> X = mk<T>(hs * (A + wo.y), hs * (B - wo.x)), Y = mk<T>(hs * (A - wo.y), hs * (-B - wo.x));
 #ifdef QI_STFT_DBG
-      if (a.dbg & 1) {
+      if (a.dbg & 1) {  // no panel stores (the arithmetic is kept alive by a store that never happens)
+        const T p = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
         const T b = (a.dbg & 8) ? p : log2_t(sqrt_t(p) + eps);
         if (b == T(12345.678)) *zp = X;
         continue;
       }
-      if (a.dbg & 8) {
+      if (a.dbg & 8) {  // coefficients only
         *zp = X;
+        if (2 * k != M) *zq = Y;
         continue;
       }
 #endif
-#ifdef QI_STFT_NT
-      stream_store(zp, X);
-      __builtin_nontemporal_store(log2_t(sqrt_t(p) + eps), bp);
-#else
       *zp = X;
-      *bp = log2_t(sqrt_t(p) + eps);
-#endif
+      *bp = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
+      if (2 * k != M) {
+        *zq = Y;
+        *bq = log2_t(sqrt_t(Y.x * Y.x + Y.y * Y.y) + eps);
+      }
     }
     return;
   }
