@@ -1342,7 +1342,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
 }
 
 // float64 records (run_native64): the same band items in double arithmetic -- Gaussian filter spectra in registers, no
-// narrow-spectrum shortcuts (those drop weights below 2^-30 of the peak), no long blocks, no split bands.  The exchange
+// narrow-spectrum shortcuts (those drop weights below 2^-30 of the peak), no long blocks; split bands through k_block64_edge.  The exchange
 // buffer and the twiddle table take 72 KB of (dynamic) LDS: two workgroups per CU, compiled for two waves per SIMD.
 constexpr size_t kBlk64Lds = (size_t)(kBlkBuf + 256) * sizeof(double2);
 template <bool DEMOD, bool COEF, bool BITS>

@@ -321,7 +321,7 @@ struct qi_plan {
   int native_z64 = 1;      // float64: narrow-spectrum bands at the decimated rate (coarse inverse FFT + 16-tap interpolation)
   int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
   double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level
-  int native_f64 = 1;      // float64 plans run the two-pass kernels (exact algorithm, double arithmetic) at 2^20 / 2^21-point transforms
+  int native_f64 = 1;      // float64 plans run on the native engines in double arithmetic (2^20 / 2^21-point transforms)
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen
                                 // inputs batched: -35 % of that stage at 16 records, -20 % at one); 0: never

@@ -779,9 +779,11 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   return QI_OK;
 }
 
-// float64 records on the native two-pass kernels (exact algorithm: no truncated atoms, no interpolation): forward
-// transform of the records by hipFFT, then per launch group pass 1 for the wide bands and pass 2 with the pruned loader
-// and the fused epilogue for every band, one tail launch.  8-row workgroups (Cfg<double, 8>).
+// float64 records on the native engines in double arithmetic: forward transform of the records by hipFFT; the bands the
+// float64 zoom takes (one gather + batched hipFFT + interpolation launch per coarse-grid level; split bands leave their
+// tapered part in scratch), the block engine's bands (k_block64) and the split bands' edge items (k_block64_edge); whatever
+// is left on the exact two-pass kernels (per launch group pass 1 for the wide bands, pass 2 with the pruned loader and
+// the fused epilogue, 8-row workgroups, Cfg<double, 8>); one tail launch.
 int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
   using T = double;
   const auto& t = p->nat[kind];
