@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
                     help="index into BASELINE.json configs; default: configs[1] as `value` plus the configs[2] and float64 legs "
                          "under their own keys (one rank), configs[3] = 64 records per GPU (N ranks)")
-    ap.add_argument("--legs", default="", help="comma list of the default run's legs to keep (main, configs2, f64, configs1_per_gpu)")
+    ap.add_argument("--legs", default="", help="comma list of the default run's legs to keep (main, configs2, f64, configs4, configs1_per_gpu)")
     ap.add_argument("--settle-ms", type=float, default=3000.0,
                     help="after the warmup steps, keep stepping (untimed) until this much wall time has passed since "
                          "their start: the GPU leaves its idle clocks only after ~0.1 s of load, and a GPU phase of a few "
@@ -74,6 +74,9 @@ def parse():
                     help="1: CPU rehearsal of the multi-rank plumbing (gloo, no GPU): the transforms are replaced by a stub that "
                          "writes rank- and step-dependent reduced products; everything else -- sharding, message buffers, the "
                          "pipelined gather, the barriers and the max-over-ranks timing, the JSON line -- is the real code")
+    ap.add_argument("--stub-ms", type=float, default=0.0,
+                    help="with --stub: every stub transform call takes this long (a fixed step time, so that a rehearsed N-rank "
+                         "line can be checked against N x the one-rank line)")
     ap.add_argument("--stub-dump", default="", help="with --stub: rank 0 saves the last gathered buffers here (torch.save)")
     return ap.parse_args()
 
@@ -89,6 +92,22 @@ def survey_bytes(n_ch, n_b, n, length, real_bytes):
     engine never reads such a bank (its filters are evaluated in registers / from compact windows); kept as a labelled
     second number only."""
     return 2 * required_bytes(n_ch, n_b, n, real_bytes) + n_b * length * 2 * real_bytes
+
+
+FP64_VALU_PEAK_GINST = 1024 * 2.4 / 4  # wave instructions / ns: 1024 SIMDs x 2.4 GHz, a double-precision wave64 instruction
+# issues over 4 cycles (78.6 TFLOP/s of float64 vector FMA = 614.4 G wave-FMAs / s x 64 lanes x 2)
+
+
+def load_traffic():
+    """profiles/traffic.json: per-launch HBM bytes and per-item instruction counts from the builder's rocprofv3 --pmc passes of
+    the same commands (kept under profiles/; not collected in the run that prints them)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            return json.load(open(tfile))
+        except Exception:
+            pass
+    return {}
 
 
 # ---- CPU baseline (the oracle port), before anything touches the GPU: plain forked workers ----------------------------
@@ -199,7 +218,7 @@ def stream_bench(args, ctx, cpu):
         rows[c] = np.tile(np.roll(base, 7919 * c), reps)[:total] + noise[7919 * c : 7919 * c + total]
     host = OwnedRecords((n_ch * world, total), n_ch * rank, rows)
     if stub:
-        plan = StubPlan(n, n_b, rank, dtype=tdtype)
+        plan = StubPlan(n, n_b, rank, dtype=tdtype, step_ms=args.stub_ms)
     else:
         plan = qi.TfrPlan(n, tdtype, dev, qi.TfrPlan.workspace_for(n, n_b, tdtype, n_ch, cap_bytes=32 << 30))
         plan.set_styx_bank(order, fs)
@@ -273,6 +292,24 @@ def stream_bench(args, ctx, cpu):
                         "(see the f64 leg / --dtype f64 for the stage breakdown of the float64 engines)",
             },
         }
+        # No panel byte is stored here, so the HBM roofline does not bound this leg: its kernels are priced against the
+        # double-precision vector issue rate.  Instructions per item = SQ_INSTS_VALU summed over the kernels of one item
+        # (rocprofv3 --pmc pass of this command, profiles/), achieved = that count over the measured time per item.
+        tdata = load_traffic()
+        insts = tdata.get(f"valu_wave_insts_per_item:{args.dtype}:n{args.log2n}:o{order:g}:c{n_ch}:stream")
+        item_ms = dt / max(done, 1) * 1e3
+        ach = insts / (item_ms * 1e6) if insts else None  # wave instructions per nanosecond = G / s
+        line["roofline"] = {
+            "bound": "fp64-valu" if args.dtype == "f64" else "fp32-valu", "kernel": "all kernels of one streamed item",
+            "achieved": round(ach, 2) if ach else None, "peak": FP64_VALU_PEAK_GINST if args.dtype == "f64" else 2 * FP64_VALU_PEAK_GINST,
+            "unit": "G wave-instructions/s", "frac": round(ach / FP64_VALU_PEAK_GINST, 4) if (ach and args.dtype == "f64") else None,
+            "traffic": tdata.get(f"item:{args.dtype}:n{args.log2n}:o{order:g}:c{n_ch}:stream"),
+            "valu_wave_instructions_per_item": insts,
+            "valu_instructions_per_output": round(insts * 64 / points_item, 2) if insts else None,
+            "source": (tdata.get("source_f64", "profiles/") + " (SQ_INSTS_VALU / TCC passes of this command, not collected in this run)") if insts else None,
+            "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per double-precision wave64 instruction; every vector instruction is "
+                    "counted as if it were double precision (an upper bound of the issue time the kernels need)",
+        }
         if cpu:
             line["cpu_baseline"] = cpu
     plan.close()
@@ -288,11 +325,12 @@ def stream_bench(args, ctx, cpu):
 class StubPlan:
     """Stand-in for TfrPlan in --stub runs: no kernel, deterministic reduced products on the CPU."""
 
-    def __init__(self, n, n_b, rank, dtype=None):
+    def __init__(self, n, n_b, rank, dtype=None, step_ms=0.0):
         import torch
 
         self.n, self.n_b, self.rank, self.calls = n, n_b, rank, 0
         self.rdtype, self.device = dtype or torch.float32, torch.device("cpu")
+        self.step_ms = step_ms
 
     def cwt_stx(self, sig, coef=True, bits=False, reductions=False, power_scale=1.0, eps=0.0, out=None, reduced_out=None):
         import torch
@@ -300,6 +338,8 @@ class StubPlan:
         from quantum_inferno_amd.engine import TfrResult
 
         n_ch = sig.shape[0]
+        if self.step_ms > 0:
+            time.sleep(self.step_ms * 1e-3)
         if out is None:
             out = []
             for k in range(2):
@@ -425,7 +465,7 @@ def run_leg(a, ctx, cpu, extras=True):
     depth = 2 if world > 1 else 1
     ws, budget = fit_workspace(a, ctx, n, n_b, tdtype, real_bytes, depth)
     if stub:
-        plan = StubPlan(n, n_b, rank)
+        plan = StubPlan(n, n_b, rank, step_ms=a.stub_ms)
         sig = torch.zeros((n_ch, n), dtype=tdtype)
         stft = None
     else:
@@ -531,26 +571,28 @@ def run_leg(a, ctx, cpu, extras=True):
     rank_dt = [dt_local]
     wait_ms = [pipe.wait_ms() / max(a.steps, 1)]
     n_ranks = 1
+    # every rank's stage times (HIP events, the 3 untimed steps with every stage timed): a slow rank 0 -- RCCL's copy kernels
+    # share its CUs with the transforms -- then shows as longer kernels THERE, apart from the time spent waiting for a gather
+    stage_names = sorted(k for k, v in stage_all.items() if v[1])
+    rank_stage_ms = {k: [round(stage_all[k][0] / 3, 4)] for k in stage_names}
     if world > 1:
         n_ranks = dist.get_world_size()
-        t = torch.tensor([dt, wait_ms[0]], dtype=torch.float64, device=dev)
+        from quantum_inferno_amd._lib import STAGES as all_stages
+
+        t = torch.tensor([dt, wait_ms[0]] + [stage_all.get(k, (0.0, 0))[0] / 3 for k in all_stages], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         rank_dt = [float(v[0].item()) for v in every]
         wait_ms = [float(v[1].item()) for v in every]
+        rank_stage_ms = {k: [round(float(v[2 + i].item()), 4) for v in every] for i, k in enumerate(all_stages)
+                         if any(float(v[2 + i].item()) > 0 for v in every)}
         dt = max(rank_dt)
 
     line = None
     if rank == 0:
         points_step = 2 * total_ch * n_b * n
         value = points_step * a.steps / dt / 1e6
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        tdata = {}
-        if os.path.exists(tfile):
-            try:
-                tdata = json.load(open(tfile))
-            except Exception:
-                tdata = {}
+        tdata = load_traffic()
 
         def stage_roofline(name):
             """Algorithmic bytes of a stage -- the complex coefficients of the bands it produces, written once (SURVEY
@@ -624,6 +666,7 @@ def run_leg(a, ctx, cpu, extras=True):
                 "rank_seconds": [round(v, 6) for v in rank_dt],
                 "gather_wait_ms_per_step": [round(v, 4) for v in wait_ms] if pipe.timing else None,
                 "gather_message_bytes_per_rank": int(2 * slots * 8) if world > 1 else 0,
+                "rank_stage_ms_per_step": rank_stage_ms if world > 1 else None,
             },
             "roofline": stage_roofline(dominant),
             "step_roofline": {
@@ -734,7 +777,8 @@ def main():
     elif world == 1:
         legs = [("", leg_args(args, 1), args.cpu_seconds),
                 ("configs2", leg_args(args, 2), min(args.cpu_seconds, 12.0)),
-                ("f64", leg_args(args, 2, channels=4, dtype="f64", stft=0), min(args.cpu_seconds, 9.0))]
+                ("f64", leg_args(args, 2, channels=4, dtype="f64", stft=0), min(args.cpu_seconds, 9.0)),
+                ("configs4", leg_args(args, 4), min(args.cpu_seconds, 9.0))]
     else:
         legs = [("", leg_args(args, 2), 0.0), ("configs1_per_gpu", leg_args(args, 1), 0.0)]
     if args.legs:
@@ -764,6 +808,7 @@ def main():
         backend = dist.get_backend() + (" (RCCL over xGMI)" if not stub else "")
     if stub:
         dev = torch.device("cpu")
+        torch.set_num_threads(1)  # (as under torch.distributed.run: the stub's small fills otherwise pay for a thread pool)
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
@@ -783,9 +828,18 @@ def main():
             else:
                 line[key] = rec
     if rank == 0:
-        if composite and world > 1:
-            line["scaling_note"] = ("weak scaling of BASELINE configs[3] (64 records per GPU): the one-GPU point of this curve is the "
-                                    "`configs2` record of the N = 1 line (whose `value` is configs[1], one record)")
+        if composite:
+            # `value` of an N-rank default run is BASELINE configs[3] (64 records per GPU), `value` of the one-rank default run is
+            # configs[1] (one record): a scaling curve must start from `scaling_base`, not from the one-rank `value`
+            line["scaling_note"] = ("weak scaling of BASELINE configs[3] (64 records per GPU, order 12, STFT+CWT+STX+entropy): with N > 1 "
+                                    "ranks `value` is that workload; the one-GPU point of the curve is `scaling_base` of the N = 1 line "
+                                    "(= its `configs2` record; the N = 1 `value` itself is configs[1], one record)")
+            base = line.get("configs2") if world == 1 else None
+            if base:
+                line["scaling_base"] = {"workload": base["config"]["workload"], "value": base["value"], "unit": base["unit"],
+                                        "ms_per_step": base["ms_per_step"], "n_gpus": base["n_gpus"],
+                                        "channels_per_gpu": base["config"]["channels_per_gpu"],
+                                        "points_per_step": base["config"]["points_per_step"]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

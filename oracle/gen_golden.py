@@ -390,5 +390,8 @@ if __name__ == "__main__":
         gen_sized(20, (12,), 1000.0, "large_n1048576_o12_ch63_stx.npz", all_rows=True, channel=(63, 64), transforms=("stx",))
     if "o6n19" in todo:  # an order-6 table at 2^19 samples: other zoom classes / reach groups than orders 3 and 12 at 2^20
         gen_sized(19, (6,), 1000.0, "large_n524288_o6.npz", all_rows=True, transforms=("cwt", "stx"))
+    if "large12f64" in todo:  # the order-12 table on a FLOAT64 record (the shape of BASELINE configs[4] per chunk and of the
+        # bench's f64 leg): every band of both panels from the reference working in double throughout; ~30 GB RSS, ~8 min
+        gen_sized(20, (12,), 1000.0, "large_n1048576_o12_f64.npz", all_rows=True, dtype=np.float64, transforms=("cwt", "stx"))
     if "large12" in todo:  # BASELINE configs[2] per channel: order 12 (167 bands) at 2^20 samples; ~30 GB RSS, ~6 min
         gen_sized(20, (12,), 1000.0, "large_n1048576_o12.npz", all_rows=True)

@@ -15,10 +15,12 @@ int stft_impl(int device, const void* sig, int64_t C, int64_t n, const void* win
   const int64_t nseg = qi_stft_segments(n, seg, hop);
   const int64_t nf = nfft / 2 + 1;
   static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
-  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft))  // one kernel: segments, transform and store from LDS
-    return launch_stft_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<cplx<T>*>(Z),
-                                static_cast<T*>(bits), C, n, seg, hop, nfft, nseg, seg / 2, scale,
-                                eps == 0.0 ? 2.220446049250313e-16 : eps, st);
+  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft)) {  // one kernel: segments, transform and store from LDS
+    const int rc = launch_stft_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<cplx<T>*>(Z),
+                                        static_cast<T*>(bits), C, n, seg, hop, nfft, nseg, seg / 2, scale,
+                                        eps == 0.0 ? 2.220446049250313e-16 : eps, st);
+    if (rc != QI_ERR_UNSUPPORTED) return rc;  // (a device with less LDS per workgroup than the tile needs: the three-kernel path below)
+  }
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
@@ -37,9 +39,11 @@ int welch_impl(int device, const void* sig, int64_t C, int64_t n, const void* wi
   const int64_t nseg = (n - seg) / hop + 1;
   const int64_t nf = nfft / 2 + 1;
   static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
-  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft))  // segments, transform, |X|^2 sums in one kernel
-    return launch_welch_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<T*>(pxx),
-                                 reinterpret_cast<double*>(scratch), C, n, seg, hop, nfft, nseg, scale * scale, st);
+  if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft)) {  // segments, transform, |X|^2 sums in one kernel
+    const int rc = launch_welch_fused<T>(static_cast<const T*>(sig), static_cast<const T*>(window), static_cast<T*>(pxx),
+                                         reinterpret_cast<double*>(scratch), C, n, seg, hop, nfft, nseg, scale * scale, st);
+    if (rc != QI_ERR_UNSUPPORTED) return rc;
+  }
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_stft_frames<T>(static_cast<const T*>(sig), static_cast<const T*>(window), frames, C, n, seg, hop,
@@ -63,7 +67,8 @@ int sliding_stft_impl(int device, const T* sig, int64_t C, int64_t n, const T* w
   if (!fused_off && stft_fused_supported(sizeof(T) == 8 ? QI_F64 : QI_F32, seg, hop, nfft)) {
     // one kernel: slices (padding mode, optional detrend), transform, phase roll, [frequency][slice] store
     const StftSliding sl{pad_mode, detrend, R ? kind : 0, roll};
-    return launch_stft_fused<T>(sig, window, Z, R, C, n, seg, hop, nfft, nseg, -first, 1.0, 0.0, st, nullptr, &sl);
+    const int rc = launch_stft_fused<T>(sig, window, Z, R, C, n, seg, hop, nfft, nseg, -first, 1.0, 0.0, st, nullptr, &sl);
+    if (rc != QI_ERR_UNSUPPORTED) return rc;
   }
   T* frames = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));

@@ -48,8 +48,18 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 #else
+// PRECONDITION of wave_sum / wave_max below: the WHOLE wave is active (call them after the loops have reconverged, never
+// inside a divergent branch).  The row reductions run under EXEC, but the last step reads lanes 0, 16, 32 and 48 with
+// v_readlane, which ignores EXEC: an inactive one of those lanes would hand back stale register contents.  -DQI_WAVE_SHFL
+// selects the shuffle trees above, which only need lane 0; -DQI_NATIVE_DEBUG builds trap on a partial wave.
+__device__ __forceinline__ void wave_full_check() {
+#ifdef QI_NATIVE_DEBUG
+  if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
+  wave_full_check();
   v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
   v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
   v += dpp_mov<0x141>(v);  // row_half_mirror
@@ -58,6 +68,7 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 template <typename T>
 __device__ __forceinline__ T wave_max(T v) {
+  wave_full_check();
   T w = dpp_mov<0xB1>(v);
   v = w > v ? w : v;
   w = dpp_mov<0x4E>(v);

@@ -11,6 +11,7 @@ PyTorch is used for device memory and streams only.
 import collections
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -495,6 +496,7 @@ def finish(result_tensor, was_numpy, was_1d, widen=False):
 
 
 PINNED_RESULT_MAX_BYTES = 4 << 30  # larger results are staged through two fixed buffers into pageable memory
+STAGE_PIECE_BYTES = 64 << 20  # bytes per staged piece (<= the 64 MiB staging buffers; tests lower it to exercise many pieces)
 
 
 def _trim_pinned_cache():
@@ -510,29 +512,36 @@ def _trim_pinned_cache():
 
 _STAGE_BYTES = 64 << 20
 _STAGE = []  # two page-locked staging buffers, made once (PyTorch's pinned allocator never unpins what it freed)
+_STAGE_LOCK = threading.Lock()  # the two buffers are shared by every caller of finish(): one staged copy at a time
+_NUMPY_OF = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64, torch.complex128: np.complex128,
+             torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8}
 
 
 def _staged_copy(t):
     """Device tensor -> pageable NumPy array through two fixed page-locked buffers: the device-to-host copy of piece k + 1
     runs while piece k is copied out of its staging buffer, and no page-locked memory grows with the result (an order-12
     panel is 1.6 GB and more once widened)."""
-    if not _STAGE:
-        _STAGE.extend(torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2))
+    if t.dtype not in _NUMPY_OF:
+        raise TypeError(f"no NumPy dtype for a {t.dtype} result")
     flat = t.reshape(-1).view(torch.uint8) if not t.is_complex() else torch.view_as_real(t).reshape(-1).view(torch.uint8)
-    out = np.empty(t.shape, dtype=np.dtype(str(t.dtype).replace("torch.", "")))
+    out = np.empty(t.shape, dtype=_NUMPY_OF[t.dtype])
     dst = torch.from_numpy(out.reshape(-1).view(np.uint8))
     total = flat.numel()
     stream = torch.cuda.current_stream(t.device)
     events = [torch.cuda.Event(), torch.cuda.Event()]
-    pieces = [(o, min(_STAGE_BYTES, total - o)) for o in range(0, total, _STAGE_BYTES)]
-    for k, (o, m) in enumerate(pieces):
-        _STAGE[k & 1][:m].copy_(flat[o : o + m], non_blocking=True)
-        events[k & 1].record(stream)
-        if k:
-            po, pm = pieces[k - 1]
-            events[(k - 1) & 1].synchronize()
-            dst[po : po + pm].copy_(_STAGE[(k - 1) & 1][:pm])
-    po, pm = pieces[-1]
-    events[(len(pieces) - 1) & 1].synchronize()
-    dst[po : po + pm].copy_(_STAGE[(len(pieces) - 1) & 1][:pm])
+    piece = min(_STAGE_BYTES, max(int(STAGE_PIECE_BYTES), 4096))
+    pieces = [(o, min(piece, total - o)) for o in range(0, total, piece)]
+    with _STAGE_LOCK:
+        if not _STAGE:
+            _STAGE.extend(torch.empty(_STAGE_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2))
+        for k, (o, m) in enumerate(pieces):
+            _STAGE[k & 1][:m].copy_(flat[o : o + m], non_blocking=True)
+            events[k & 1].record(stream)
+            if k:
+                po, pm = pieces[k - 1]
+                events[(k - 1) & 1].synchronize()
+                dst[po : po + pm].copy_(_STAGE[(k - 1) & 1][:pm])
+        po, pm = pieces[-1]
+        events[(len(pieces) - 1) & 1].synchronize()
+        dst[po : po + pm].copy_(_STAGE[(len(pieces) - 1) & 1][:pm])
     return out

@@ -9,8 +9,8 @@ from ..scales_dyadic import get_epsilon
 
 
 def to_log2_with_epsilon(x: Union[np.ndarray, float, list]) -> Union[np.ndarray, float]:
-    """log2(|x| + eps): amplitude bits, complex input allowed (ref rescaling.py:13-20).  NumPy / scalar input: float64 as
-    in the reference.  A CUDA tensor goes through the library's kernel (qi_log2_abs) and keeps its precision: float32 /
+    """log2(|x| + eps): amplitude bits, complex input allowed (ref rescaling.py:13-20).  NumPy / scalar / host-tensor input: a float64
+    NumPy result as in the reference.  A CUDA tensor goes through the library's kernel (qi_log2_abs) and keeps its precision: float32 /
     complex64 in -> float32 bits (the reference, NumPy only, would return float64; cast the input to double to get that)."""
     try:
         import torch
@@ -20,8 +20,8 @@ def to_log2_with_epsilon(x: Union[np.ndarray, float, list]) -> Union[np.ndarray,
         from .. import tfr_info  # device tensors: the library's log2 kernel (qi_log2_abs), not a PyTorch expression
 
         return tfr_info.log2_abs(x, float(get_epsilon()))
-    if torch is not None and isinstance(x, torch.Tensor):  # a host tensor stays a tensor (and keeps its autograd graph)
-        return torch.log2(torch.abs(x) + float(get_epsilon()))
+    if torch is not None and isinstance(x, torch.Tensor):  # a host tensor is NumPy data: float64 array out, as the signature says
+        x = x.detach().numpy()
     return np.log2(np.abs(x) + get_epsilon())
 
 

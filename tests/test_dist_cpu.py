@@ -217,3 +217,31 @@ def test_bench_stream_items_sharded_world2(tmp_path):
     assert line["config"]["rank_items"] == [chunks - 2, chunks - 2] and line["steps"] == chunks - 2
     assert line["config"]["world_size"] == 2 and line["n_gpus"] == 2
     assert line["config"]["points_per_step"] == 2 * block * line["config"]["bands"] * n * 2
+
+
+def test_bench_scaling_base_consistent_with_multirank_value_world2():
+    """The one-GPU point of the weak-scaling curve is machine-readable in the N = 1 line (`scaling_base` = its configs2 record:
+    the N = 1 `value` itself is configs[1], another workload) and consistent with the N-rank line: with the stub's fixed step
+    time the two-rank `value` is ~2 x `scaling_base.value`, `points_per_step` doubles, both lines carry `scaling_note`, and the
+    N-rank line has every rank's stage times."""
+    import json
+    import subprocess
+
+    common = ["--steps", "2", "--warmup", "1", "--stub", "1", "--stub-ms", "400", "--log2n", "12", "--settle-ms", "0"]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--legs", "main,configs2", *common],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    one = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    base = one["scaling_base"]
+    assert one["config"]["channels_per_gpu"] == 1 and "configs[1]" in one["config"]["workload"]
+    assert base["value"] == one["configs2"]["value"] and base["channels_per_gpu"] == 64 and base["n_gpus"] == 1
+    assert "configs[2]" in base["workload"] and "scaling_note" in one
+    assert base["points_per_step"] == 2 * 64 * one["configs2"]["config"]["bands"] * 4096
+    two = _torchrun(["--legs", "main", *common])
+    assert "configs[3]" in two["config"]["workload"] and "scaling_note" in two and "scaling_base" not in two
+    assert two["config"]["points_per_step"] == 2 * base["points_per_step"]
+    assert abs(two["value"] / base["value"] - 2.0) < 0.3, (two["value"], base["value"])
+    assert abs(two["value"] - two["config"]["points_per_step"] * two["steps"] / max(two["config"]["rank_seconds"]) / 1e6) <= 1e-3 * two["value"]
+    stages = two["config"]["rank_stage_ms_per_step"]
+    assert stages and all(len(v) == 2 for v in stages.values()) and "block" in stages and "zoom" in stages

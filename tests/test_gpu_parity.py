@@ -636,6 +636,84 @@ def test_float64_native_engine_vs_oracle(golden, order):
     ref.close()
 
 
+@pytest.mark.parametrize("channels,fs,ws_cap", [(4, 1000.0, 48 << 30), (16, 800.0, 32 << 30)])
+def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
+    """The float64 engines at the shapes that are TIMED: 4 records x order 12 x 2^20 through `cwt_stx` (bench.py's f64 leg,
+    1 kHz, 48 GiB scratch cap) and 16 records at 800 Hz with a 32 GiB cap (one item of the configs[4] streaming leg: the records
+    pass in tiles), with the panels stored and with `coef=False` (streaming keeps the reduced product only).
+      * every record against its single-record run (coefficients bit for bit: the same kernels; the reductions to 1e-12 --
+        the per-time planes of a batch are cut differently);
+      * record 0 against the oracle at 1e-10 on bands of every engine: all 14 split bands (float64 zoom + k_block64_edge),
+        zoom bands of several grids, block bands of both k_block64 variants (styx / Stockwell demodulation);
+      * at 1 kHz record 0 against the REFERENCE run on the same float64 record, every band of both panels and every
+        reduction (large_n1048576_o12_f64.npz; the reference is complex128 throughout: styx_stx.py:228, styx_cwt.py:195-198);
+      * the reductions of `coef=False` equal those of the stored-panel call bit for bit, and the per-band powers equal a direct
+        sum over the stored panel (tfr_info.py:82-94)."""
+    n, order = 1 << 20, 12
+    tol = TOL[np.float64]
+    f = scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
+    nb = len(f)
+    assert nb == 167
+    recs = [orc.synth_chirp(n, fs, dtype=np.float64)] + [orc.synth_chirp(n, fs, c, channels, np.float64) for c in range(1, channels)]
+    x = torch.from_numpy(np.stack(recs)).cuda()
+    plan = engine.TfrPlan(n, np.float64, None, engine.TfrPlan.workspace_for(n, nb, np.float64, channels, cap_bytes=ws_cap))
+    plan.set_styx_bank(order, fs)
+    plan.set_stx_bands(order, fs)
+    knobs = ("QI_NATIVE_SPLIT", "QI_NATIVE_SPLIT64", "QI_NATIVE_Z64", "QI_NATIVE_BLOCK64")
+    if not any(k in os.environ for k in knobs):
+        assert plan.stage_bands("pass2")[0] == 0 and plan.stage_bands("pass2")[2] == 0
+        assert plan.stage_bands("block")[0] >= 14 + 20 and plan.stage_bands("block")[2] >= 20
+    full = plan.cwt_stx(x, coef=True, reductions=True)
+    lean = plan.cwt_stx(x, coef=False, reductions=True)
+    torch.cuda.synchronize()
+    for a, b in zip(full, lean):
+        assert b.coef is None and torch.equal(a.reduced, b.reduced)
+    # every record against its single-record run
+    for c in range(channels):
+        one = plan.cwt_stx(x[c : c + 1], coef=True, reductions=True)
+        for a, b, name in zip(full, one, ("cwt", "stx")):
+            assert torch.equal(a.coef[c], b.coef[0]), (name, c)
+            assert torch.allclose(a.power_band[c], b.power_band[0], rtol=1e-12, atol=0.0), (name, c)
+            assert torch.allclose(a.power_time[c], b.power_time[0], rtol=1e-11, atol=1e-13 * float(b.power_time.max())), (name, c)
+            assert torch.allclose(a.stats[c, :3], b.stats[0, :3], rtol=1e-12), (name, c)
+        del one
+    # the fused reductions against a direct reduction of the stored panels (one record at a time: 2.8 GB each)
+    for a, name in zip(full, ("cwt", "stx")):
+        for c in (0, channels - 1):
+            p = a.coef[c].real ** 2 + a.coef[c].imag ** 2
+            assert torch.allclose(a.power_band[c], p.sum(dim=1), rtol=1e-10), name
+            assert torch.allclose(a.power_time[c], p.sum(dim=0), rtol=1e-9, atol=1e-12 * float(p.sum(dim=0).max())), name
+            assert abs(float(a.stats[c, 0]) - float(p.max())) <= 1e-12 * float(p.max())
+            assert abs(float(a.stats[c, 1]) - float(p.sum())) <= 1e-10 * float(p.sum())
+            del p
+    # record 0 against the oracle on bands of every engine
+    picks = {"cwt": list(range(14)) + [14, 40, 90, 130, nb - 23, nb - 12, nb - 1],
+             "stx": [0, 1, 30, 90, 130, nb - 23, nb - 12, nb - 2, nb - 1]}
+    for a, name, fn in zip(full, ("cwt", "stx"), (orc.cwt_fft, orc.stx_fft)):
+        pick = picks[name]
+        _, _, want = fn(order, recs[0], fs, bands=pick)
+        got = a.coef[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        scale = float(a.coef[0].abs().max())
+        assert np.max(np.abs(got - want)) <= tol["coef"] * scale, name
+        for i, j in enumerate(pick):
+            assert np.max(np.abs(got[i] - want[i])) <= 5e-9 * np.max(np.abs(want[i])), (name, j)
+        pb = a.power_band[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        assert np.allclose(pb, (np.abs(want) ** 2).sum(axis=1), rtol=tol["red"]), name
+        # the last record too (another tile of the scratch at 16 records), on one band of each engine
+        last = [pick[0], pick[len(pick) // 2], pick[-1]]
+        _, _, want = fn(order, recs[-1], fs, bands=last)
+        got = a.coef[channels - 1][torch.tensor(last, device="cuda")].cpu().numpy()
+        assert np.max(np.abs(got - want)) <= tol["coef"] * scale, (name, "last record")
+    if fs == 1000.0:
+        g = golden("large_n1048576_o12_f64.npz")
+        assert np.max(np.abs(recs[0][:: n // 4096] - g["sig_samples"])) == 0.0 and np.array_equal(f, g["f_o12"])
+        assert len(g["rows_o12"]) == nb
+        for a, name in zip(full, ("cwt", "stx")):
+            check_digest(a, g, name, order, dict(tol, bits_floor=1e-3, row=5e-9, ent=5e-8), g["rows_o12"])
+    del full, lean
+    plan.close()
+
+
 @pytest.mark.parametrize("log2n,name", [(19, "cwt"), (21, "stx")])
 def test_float64_native_engine_other_lengths(log2n, name):
     """The float64 engines run transforms of 2^20 / 2^21 points: the zero-padded styx CWT of a 2^19-sample record and the
@@ -872,6 +950,41 @@ def test_fused_cwt_stx_call_matches_separate_calls():
     sep2 = plan.stx(x, coef=True, reductions=True)
     assert torch.equal(sep2.coef, sep_s.coef)
     plan.close()
+
+
+def test_staged_result_copy_is_bit_equal(monkeypatch):
+    """engine.finish for results above PINNED_RESULT_MAX_BYTES: the copy through the two fixed page-locked staging buffers
+    (many pieces, an odd tail) equals a plain device-to-host copy bit for bit, for every result dtype; two threads at once do
+    not disturb each other (the staging buffers are shared under a lock)."""
+    import threading
+
+    monkeypatch.setattr(engine, "PINNED_RESULT_MAX_BYTES", 1 << 20)
+    monkeypatch.setattr(engine, "STAGE_PIECE_BYTES", 3 << 20)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for dtype in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+        t = torch.randn((3, 7, 100003), dtype=dtype, device="cuda", generator=gen)
+        got = engine.finish(t, True, False)
+        assert isinstance(got, np.ndarray) and got.shape == tuple(t.shape) and np.array_equal(got, t.cpu().numpy())
+    wide = engine.finish(torch.randn((2, 5, 70001), dtype=torch.complex64, device="cuda", generator=gen), True, True, widen=True)
+    assert wide.dtype == np.complex128 and wide.shape == (5, 70001)
+    with pytest.raises(TypeError):
+        engine._staged_copy(torch.zeros(4, dtype=torch.bfloat16, device="cuda"))
+    a = torch.randn((4, 1 << 20), dtype=torch.float64, device="cuda", generator=gen)
+    b = torch.randn((4, 1 << 20), dtype=torch.float64, device="cuda", generator=gen)
+    out = {}
+
+    def work(key, t):
+        torch.cuda.set_device(0)
+        out[key] = [engine.finish(t, True, False) for _ in range(3)]
+
+    threads = [threading.Thread(target=work, args=(k, t)) for k, t in (("a", a), ("b", b))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for key, t in (("a", a), ("b", b)):
+        ref = t.cpu().numpy()
+        assert all(np.array_equal(r, ref) for r in out[key])
 
 
 def test_plan_ring_matches_single_plan():

@@ -21,6 +21,11 @@ def test_known_answer_of_reference_tests():
     # reference tests/utilities/test_rescaling.py:7-21, test_calculations.py:86-100
     assert round(float(rescaling.to_log2_with_epsilon(100.0)), 2) == 6.64
     assert round(float(rescaling.to_log2_with_epsilon(-100.0)), 2) == 6.64
+    import torch
+
+    host = rescaling.to_log2_with_epsilon(torch.tensor([100.0, -3.0], dtype=torch.float32))  # host tensor -> NumPy float64, as the
+    assert isinstance(host, np.ndarray) and host.dtype == np.float64                         # signature promises (rescaling.py:13-20)
+    assert np.array_equal(host, np.log2(np.abs(np.array([100.0, -3.0])) + sd.get_epsilon()))
     assert rescaling.is_power_of_two(8) and not rescaling.is_power_of_two(9)
     assert calculations.round_value(1.5, "round") == 2
     assert calculations.get_num_points(10, 10, "round", "log2") == 7

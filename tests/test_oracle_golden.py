@@ -292,6 +292,8 @@ def test_benchmark_length_rows(golden, order, name):
     ("large_n1048576_f64.npz", 20, 3, np.float64, (0, 1), ("cwt", "stx")),
     ("large_n1048576_o12_ch63_stx.npz", 20, 12, np.float32, (63, 64), ("stx",)),
     ("large_n524288_o6.npz", 19, 6, np.float32, (0, 1), ("cwt", "stx")),
+    # round 4: the order-12 table on a FLOAT64 record (the shape bench.py's f64 leg and the configs[4] streaming leg time)
+    ("large_n1048576_o12_f64.npz", 20, 12, np.float64, (0, 1), ("cwt", "stx")),
 ])
 def test_round3_fixtures_rows(golden, name, log2n, order, dtype, channel, transforms):
     """The oracle against the reference rows added in round 3: the benchmark record in float64 (the reference then works
