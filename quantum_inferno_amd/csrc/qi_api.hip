@@ -96,6 +96,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   }
   if (const char* e = tune_env("QI_NATIVE_F64")) p->native_f64 = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64")) p->native_z64 = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_Z64_FINE")) p->native_z64_fine = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_LEVELS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= native::kZ64Levels) p->native_z64_levels = v;
@@ -191,6 +192,8 @@ int qi_plan_destroy(qi_plan* p) {
     for (auto* b : per_cut)
       if (b) (void)hipFree(b);
   for (auto* w : p->d_z64_w)
+    if (w) (void)hipFree(w);
+  for (auto* w : p->d_z64f_w)
     if (w) (void)hipFree(w);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)

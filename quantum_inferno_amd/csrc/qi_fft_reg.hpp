@@ -275,6 +275,11 @@ __device__ __forceinline__ double plog2p(double p, const double (*tab)[2]) {
   return p >= 2.2250738585072014e-308 ? p * log2_pos(p, tab) : 0.0;
 }
 __device__ __forceinline__ double plog2p(double p) { return p >= 2.2250738585072014e-308 ? p * log2_pos(p) : 0.0; }
+// the same without a branch: p log2(max(p, smallest normal)) -- equal for every normal p and for p = 0 (0 x -1022 = 0); a
+// denormal power contributes -1022 p instead of p log2 p, below 1e-304 either way
+__device__ __forceinline__ double plog2p_flat(double p, const double (*tab)[2]) {
+  return p * log2_pos(__builtin_fmax(p, 2.2250738585072014e-308), tab);
+}
 
 }  // namespace
 }  // namespace native

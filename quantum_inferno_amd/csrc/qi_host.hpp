@@ -33,14 +33,15 @@ struct DeviceGuard {
 
 // ---- hipFFT plan cache (one per qi_plan, plus a process-wide one for the plan-less STFT entry) ----
 struct FftCache {
-  using Key = std::tuple<int, int64_t, int64_t>;  // hipfftType, length, batch
+  using Key = std::tuple<int, int64_t, int64_t, int64_t>;  // hipfftType, length, batch, distance between transforms
   std::map<Key, hipfftHandle> plans;
   void* work = nullptr;
   size_t work_bytes = 0;
   std::vector<void*> retired;  // outgrown work areas, freed with the cache
 
-  int get(hipfftType type, int64_t len, int64_t batch, hipfftHandle* out) {
-    Key k{(int)type, len, batch};
+  int get(hipfftType type, int64_t len, int64_t batch, hipfftHandle* out, int64_t dist = 0) {
+    if (dist <= 0) dist = len;
+    Key k{(int)type, len, batch, dist};
     auto it = plans.find(k);
     if (it != plans.end()) {
       *out = it->second;
@@ -52,7 +53,9 @@ struct FftCache {
     QI_FFT(hipfftSetAutoAllocation(h, 0));
     int nn[1] = {(int)len};
     size_t ws = 0;
-    QI_FFT(hipfftMakePlanMany(h, 1, nn, nullptr, 1, (int)len, nullptr, 1, (int)len, type, (int)batch, &ws));
+    QI_REQUIRE(dist >= len && dist < (1ll << 31), "fft distance out of range");
+    if (dist == len) QI_FFT(hipfftMakePlanMany(h, 1, nn, nullptr, 1, (int)len, nullptr, 1, (int)len, type, (int)batch, &ws));
+    else QI_FFT(hipfftMakePlanMany(h, 1, nn, nn, 1, (int)dist, nn, 1, (int)dist, type, (int)batch, &ws));  // (in place, padded rows)
     if (ws > work_bytes) {
       // growing the shared work area happens while a plan warms up, never in steady state.  No synchronisation: the old
       // area stays allocated (transforms already queued keep using it) until the cache is cleared
@@ -79,6 +82,8 @@ struct FftCache {
   }
 };
 
+// in-place double-precision transforms of `batch` rows of `len` points that start `dist` elements apart
+int fft_z2z_rows(FftCache& fc, double2* data, int64_t len, int64_t dist, int64_t batch, int dir, hipStream_t st);
 template <typename T>
 int fft_c2c(FftCache& fc, cplx<T>* data, int64_t len, int64_t batch, int dir, hipStream_t st);
 template <>
@@ -250,8 +255,15 @@ struct qi_plan {
     // float64 zoom (qi_zoom64.hip): the narrow-spectrum bands of a float64 table, by coarse-grid level
     native::BandDesc* d_z64 = nullptr;
     int32_t nz64 = 0, z64_first[native::kZ64Levels] = {}, z64_count[native::kZ64Levels] = {};
+    // ... the bands of the three coarsest grids by class of the fine kernel (k_z64_fine: grid, interpolator length); ranges of
+    // d_z64, a class's bands lie inside its level's range
+    int32_t zf_first[native::kZ64FineClasses] = {}, zf_count[native::kZ64FineClasses] = {};
+    double2* d_z64_lane_ph = nullptr;  // [nz64][65] carrier factors of the lanes and the step, per band of d_z64 (Gabor kinds)
+    double2* d_z64_wave_ph = nullptr;  // [Lf / kZ64FineWave] carrier factors of the waves
     void release() {
       if (d_z64) (void)hipFree(d_z64);
+      if (d_z64_lane_ph) (void)hipFree(d_z64_lane_ph);
+      if (d_z64_wave_ph) (void)hipFree(d_z64_wave_ph);
       if (d_zoom) (void)hipFree(d_zoom);
       if (d_zoom_plane_band) (void)hipFree(d_zoom_plane_band);
       if (d_bands) (void)hipFree(d_bands);
@@ -321,6 +333,8 @@ struct qi_plan {
   int native_z64 = 1;      // float64: narrow-spectrum bands at the decimated rate (coarse inverse FFT + 16-tap interpolation)
   int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
   double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level
+  double* d_z64f_w[native::kZ64FineClasses] = {};  // lane weights per class of the fine kernel
+  int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
   int native_f64 = 1;      // float64 plans run on the native engines in double arithmetic (2^20 / 2^21-point transforms)
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen

@@ -39,6 +39,13 @@ int fft_c2c<double>(FftCache& fc, double2* data, int64_t len, int64_t batch, int
   QI_FFT(hipfftExecZ2Z(h, (hipfftDoubleComplex*)data, (hipfftDoubleComplex*)data, dir));
   return QI_OK;
 }
+int fft_z2z_rows(FftCache& fc, double2* data, int64_t len, int64_t dist, int64_t batch, int dir, hipStream_t st) {
+  hipfftHandle h;
+  QI_TRY(fc.get(HIPFFT_Z2Z, len, batch, &h, dist));
+  QI_FFT(hipfftSetStream(h, st));
+  QI_FFT(hipfftExecZ2Z(h, (hipfftDoubleComplex*)data, (hipfftDoubleComplex*)data, dir));
+  return QI_OK;
+}
 template <typename T>
 int fft_r2c(FftCache& fc, T* in, cplx<T>* out, int64_t len, int64_t batch, hipStream_t st);
 template <>

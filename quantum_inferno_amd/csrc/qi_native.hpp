@@ -275,6 +275,7 @@ int launch_zoom_coarse_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int
 constexpr int kZ64Taps = 16;       // interpolator taps (oversampling >= 4: 2.8e-12 of a unit tone)
 constexpr int kZ64Tile = 4096;     // panel samples per workgroup and band (one partial slot per band and tile)
 constexpr int kZ64Levels = 5;      // coarse grids of Lf / 64 ... Lf / 4 samples (a band is oversampled >= 4 times on its grid)
+constexpr int kZ64Pad = 16;        // a band's coarse array is [kZ64Pad | M | kZ64Pad] samples: the pads repeat the other end (k_z64_pad)
 struct Z64Args {
   int64_t Lf, n, M;             // transform length, record length, coarse grid (M = Lf >> log2d)
   int32_t log2d, kind;          // fine samples per coarse sample D = 1 << log2d (64 ... 4); table kind 0 / 1 / 2
@@ -282,7 +283,7 @@ struct Z64Args {
   const BandDesc* bands;        // [nbands] device (k_lo, k_len, src_off | shift, coef, out_band)
   const cplx<double>* X;        // [C][Lf] spectra of the records
   const cplx<double>* Hc;       // compact bank (Gabor tables)
-  cplx<double>* Z;              // [C][nbands][M] coarse spectra, transformed in place to coarse samples
+  cplx<double>* Z;              // [C][nbands][kZ64Pad + M + kZ64Pad] coarse spectra, transformed in place to coarse samples
   const double* weights;        // [D][kZ64Taps] device
   double inv_len;
   float two_over_len;
@@ -300,7 +301,43 @@ struct Z64Args {
 };
 int launch_z64_gather(const Z64Args& a, int64_t n_channels, hipStream_t st);
 int launch_z64_interp(const Z64Args& a, int nchunk, int64_t n_channels, hipStream_t st);
+int launch_z64_pad(cplx<double>* Z, int64_t M, int64_t rows, hipStream_t st);  // fills the pads of `rows` coarse arrays
 void z64_weights(int log2d, double* w /*[1 << log2d][kZ64Taps]*/);
+
+// Fine stage with wave-uniform windows (k_z64_fine, round 4).  A wave-step = 64 consecutive outputs = the 64 lanes; it spans
+// S = 64 / D coarse intervals, so its window holds N + S - 1 coarse samples -- the same for every lane: one copy per wave
+// in scalar registers (taken with v_readlane from a vector register whose lane i holds coarse sample i of the wave's window),
+// operands of the lanes' fused multiply-adds; every lane carries the N + S - 1 weights of its own position in the window.  No LDS traffic per output (k_z64_interp reads 16 x 16 bytes of LDS
+// per output and is bound by that).  A band's CLASS = (coarse grid, interpolator length): the narrower a band is against
+// its grid, the shorter the interpolator that reaches the same error (worst case of a unit tone anywhere in the band, double
+// weights: 16 taps at >= 4 x oversampling 2.8e-12, 12 at >= 8 x 3.9e-13, 10 at >= 16 x 4.1e-14, 8 at >= 32 x 7.2e-14, 6 at
+// >= 64 x 2.1e-12) -- on the coarsest grid, where every narrower band lands, most bands of an order-12 table take 6 - 10 taps.
+constexpr int kZ64FineClasses = 7;  // 0..2: grids of Lf / 64, Lf / 32, Lf / 16 samples, 16 taps; 3..6: coarsest grid, 12 / 10 / 8 / 6 taps
+constexpr int kZ64FineLevels = 3;   // coarse grids the fine kernel takes (the finer two stay with k_z64_interp)
+constexpr int z64f_level(int c) { return c < kZ64FineLevels ? c : 0; }
+constexpr int z64f_ntap(int c) { return c < kZ64FineLevels ? 16 : (c == 3 ? 12 : (c == 4 ? 10 : (c == 5 ? 8 : 6))); }
+constexpr int z64f_oversampling(int c) { return c < kZ64FineLevels ? 4 : (8 << (c - kZ64FineLevels)); }
+constexpr int z64f_span(int c) { return 1 << z64f_level(c); }                  // S
+constexpr int z64f_win(int c) { return z64f_ntap(c) + z64f_span(c) - 1; }      // weights per lane
+constexpr int kZ64FineSteps = 16;                   // wave-steps per wave and band
+constexpr int kZ64FineWave = 64 * kZ64FineSteps;    // panel samples per wave and band (one partial slot per band and wave)
+struct Z64FineArgs {  // one launch = one class of one table
+  Z64Args z;  // n, Lf, kind, panel outputs, partial layouts; `bands` = the class's bands; nbands = their number; nblk = n /
+              // kZ64FineWave partial slots per band (pb_stride, stat_nblk: the strides of the partial arrays); chunk_base =
+              // the per-time plane of the launch's first row; Z = coarse samples of the class's grid level [C][lvl_bands][M]
+  int32_t cls;         // class index
+  int32_t nrow;        // rows (gridDim.y): row r takes bands r, r + nrow, ...
+  int32_t lvl_bands;   // bands of the class's grid level (record stride of its coarse storage)
+  int32_t lvl_index0;  // index of the class's first band in its level's list
+  const double* w;     // [z64f_win(cls)][64] weights of the lanes
+  const cplx<double>* lane_ph;  // Gabor kinds: [nbands][65] exp(2 pi i k_c (lane - e) / Lf), lane = 0..63, and at [64] the step
+                                // exp(2 pi i k_c 64 / Lf) (e = 1 for the zero-padded kind: the carrier of sample tau - 1)
+  const cplx<double>* wave_ph;  // [Lf / kZ64FineWave] exp(2 pi i j kZ64FineWave / Lf)
+  int32_t debug;  // QI_NATIVE_DEBUG bit mask (-DQI_NATIVE_DEBUG builds, timing experiments only: 1 no panel stores, 2 no
+                  // interpolation, 4 no entropy logarithm, 8 no per-time sums, 16 no carrier)
+};
+int launch_z64_fine(const Z64FineArgs& a, int64_t n_channels, hipStream_t st);
+void z64_fine_weights(int cls, double* w /*[z64f_win(cls)][64]*/);
 
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
 void lz_weights(int log2d, float* w /*[1 << log2d][kBlkLzTaps]*/);

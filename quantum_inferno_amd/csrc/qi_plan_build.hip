@@ -129,6 +129,47 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       if (g >= 0) lvl[g].push_back(d);
       else rest.push_back(d);
     }
+    // The three coarsest grids go through the fine kernel with wave-uniform windows (k_z64_fine), by CLASS = (grid,
+    // interpolator length): on the coarsest grid, where every narrower band lands, a band oversampled >= 8 / 16 / 32 / 64
+    // times takes 12 / 10 / 8 / 6 taps instead of 16 (classes 3..6; the same error bound, see z64f_ntap).  A class of fewer
+    // than four bands joins the next longer interpolator.
+    for (int c = 0; c < native::kZ64FineClasses; ++c) t.zf_first[c] = t.zf_count[c] = 0;
+    if (p->native_z64_fine) {
+      const int64_t M0 = Lf / 64;
+      std::vector<std::vector<native::BandDesc>> cls(native::kZ64FineClasses);
+      for (const auto& d : lvl[0]) {
+        int c = 0;
+        for (int q = native::kZ64FineClasses - 1; q >= native::kZ64FineLevels && c == 0; --q)
+          if ((int64_t)native::z64f_oversampling(q) * d.k_len <= M0) c = q;
+        cls[c].push_back(d);
+      }
+      for (int q = native::kZ64FineClasses - 1; q >= native::kZ64FineLevels; --q) {
+        if (cls[q].empty() || cls[q].size() >= 4) continue;
+        const int to = q == native::kZ64FineLevels ? 0 : q - 1;
+        cls[to].insert(cls[to].end(), cls[q].begin(), cls[q].end());
+        cls[q].clear();
+      }
+      lvl[0].clear();
+      int32_t pos = 0;
+      for (int c : {0, 3, 4, 5, 6}) {
+        t.zf_first[c] = pos;
+        t.zf_count[c] = (int32_t)cls[c].size();
+        pos += t.zf_count[c];
+        lvl[0].insert(lvl[0].end(), cls[c].begin(), cls[c].end());
+      }
+      for (int g = 1; g < native::kZ64FineLevels && g < native::kZ64Levels; ++g) {
+        t.zf_first[g] = pos;
+        t.zf_count[g] = (int32_t)lvl[g].size();
+        pos += t.zf_count[g];
+      }
+      for (int c = 0; c < native::kZ64FineClasses; ++c) {
+        if (t.zf_count[c] == 0 || p->d_z64f_w[c]) continue;
+        std::vector<double> w((size_t)native::z64f_win(c) * 64);
+        native::z64_fine_weights(c, w.data());
+        QI_HIP(hipMalloc((void**)&p->d_z64f_w[c], w.size() * sizeof(double)));
+        QI_HIP(hipMemcpy(p->d_z64f_w[c], w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+      }
+    }
     std::vector<native::BandDesc> z;
     for (int g = 0; g < native::kZ64Levels; ++g) {
       t.z64_first[g] = (int32_t)z.size();
@@ -147,9 +188,35 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       QI_HIP(hipMalloc((void**)&t.d_z64, z.size() * sizeof(native::BandDesc)));
       QI_HIP(hipMemcpy(t.d_z64, z.data(), z.size() * sizeof(native::BandDesc), hipMemcpyHostToDevice));
     }
+    if (!z.empty() && p->native_z64_fine && kind != 2) {
+      // carrier factors of the fine kernel (Gabor kinds), exact integer phases evaluated in long double: per band
+      // exp(2 pi i k_c (lane - e) / Lf) for the 64 lanes and the step exp(2 pi i k_c 64 / Lf); per table the waves' factors
+      // exp(2 pi i j kZ64FineWave / Lf).  e = 1 for the zero-padded kind (the carrier of full-length sample tau - 1).
+      const long double two_pi = 6.283185307179586476925286766559005768L;
+      const int e = kind == 0 ? 1 : 0;
+      auto root = [&](int64_t m) {
+        m = ((m % Lf) + Lf) % Lf;
+        const long double ang = two_pi * (long double)m / (long double)Lf;
+        return make_double2((double)cosl(ang), (double)sinl(ang));
+      };
+      std::vector<double2> lane(z.size() * 65);
+      for (size_t j = 0; j < z.size(); ++j) {
+        const int64_t kc = (int64_t)z[j].k_lo + z[j].k_len / 2;
+        for (int l = 0; l < 64; ++l) lane[j * 65 + l] = root(kc * (l - e));
+        lane[j * 65 + 64] = root(kc * 64);
+      }
+      const int64_t nw = Lf / native::kZ64FineWave;
+      std::vector<double2> wave((size_t)nw);
+      for (int64_t j = 0; j < nw; ++j) wave[(size_t)j] = root(j * native::kZ64FineWave);
+      QI_HIP(hipMalloc((void**)&t.d_z64_lane_ph, lane.size() * sizeof(double2)));
+      QI_HIP(hipMemcpy(t.d_z64_lane_ph, lane.data(), lane.size() * sizeof(double2), hipMemcpyHostToDevice));
+      QI_HIP(hipMalloc((void**)&t.d_z64_wave_ph, wave.size() * sizeof(double2)));
+      QI_HIP(hipMemcpy(t.d_z64_wave_ph, wave.data(), wave.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
     if (tune_env("QI_NATIVE_VERBOSE"))
-      fprintf(stderr, "[qi plan] table %d: float64 zoom bands per level %d %d %d %d %d, two-pass bands %zu\n", kind, t.z64_count[0],
-              t.z64_count[1], t.z64_count[2], t.z64_count[3], t.z64_count[4], rest.size());
+      fprintf(stderr, "[qi plan] table %d: float64 zoom bands per level %d %d %d %d %d (fine classes %d %d %d | %d %d %d %d), two-pass bands %zu\n",
+              kind, t.z64_count[0], t.z64_count[1], t.z64_count[2], t.z64_count[3], t.z64_count[4], t.zf_count[0], t.zf_count[1],
+              t.zf_count[2], t.zf_count[3], t.zf_count[4], t.zf_count[5], t.zf_count[6], rest.size());
     bands.swap(rest);
   }
   t.h_rows.clear();

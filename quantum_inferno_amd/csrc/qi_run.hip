@@ -818,21 +818,40 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   }
   // partial slots per band: the row groups of the two-pass kernels (the circular sub-table has half as many) or the tiles
   // of the float64 zoom, whichever is more
-  const int64_t nblk_z = n / native::kZ64Tile;
+  // (the fine kernel's waves fill one slot per band and kZ64FineWave samples, k_z64_interp's workgroups one per kZ64Tile)
+  bool fine = false;
+  for (int c = 0; c < native::kZ64FineClasses; ++c) fine = fine || t.zf_count[c] > 0;
+  const int64_t nblk_z = fine ? n / native::kZ64FineWave : n / native::kZ64Tile;
   int64_t nblk = subs[0].nblk > nblk_z ? subs[0].nblk : nblk_z;
   if (p->blk[kind].ready && kind != 1 && p->blk[kind].max_blocks > nblk) nblk = p->blk[kind].max_blocks;
   // (some bands leave slots unwritten: the block bands fill one slot per block of their reach group)
   const bool clear_parts = shorts || subs[0].nblk != nblk || (p->blk[kind].ready && kind != 1);
-  // float64 zoom bands: one launch per coarse-grid level, its bands dealt to `zchunk` workgroups per tile
+  // float64 zoom bands.  Coarse stage per grid level (gather, batched transform, pads; the levels' coarse arrays lie side by
+  // side); fine stage: one k_z64_fine launch per class of the three coarsest grids, its bands dealt to `frow` rows, and one
+  // k_z64_interp launch per finer level, its bands dealt to `zchunk` workgroups per tile.
   int zchunk[native::kZ64Levels] = {};
-  size_t e_z = 0;  // coarse storage of the largest level (the levels run one after the other)
+  int frow[native::kZ64FineClasses] = {};
+  size_t z_off[native::kZ64Levels] = {};  // per record: offset (elements) of a level's coarse arrays
+  size_t e_z = 0;
+  const int64_t tiles_f = n / ((int64_t)native::kZ64FineWave * 4);
   for (int g = 0; g < native::kZ64Levels; ++g) {
     if (t.z64_count[g] == 0) continue;
-    int nc = (int)ceil_div(p->native_wgs, nblk_z * C);
+    z_off[g] = e_z / sizeof(cplx<T>);
+    e_z += (size_t)t.z64_count[g] * (size_t)(((Lf / 64) << g) + 2 * native::kZ64Pad) * sizeof(cplx<T>);
+    if (fine && g < native::kZ64FineLevels) continue;
+    int nc = (int)ceil_div(p->native_wgs, (n / native::kZ64Tile) * C);
     zchunk[g] = nc < 1 ? 1 : (nc > t.z64_count[g] ? t.z64_count[g] : nc);
     chunk_total += zchunk[g];
-    const size_t bytes = (size_t)t.z64_count[g] * (size_t)((Lf / 64) << g) * sizeof(cplx<T>);
-    if (bytes > e_z) e_z = bytes;
+  }
+  for (int c = 0; c < native::kZ64FineClasses; ++c) {
+    if (t.zf_count[c] == 0) continue;
+    // rows by work: a class's share of the launch budget (a band costs two fused multiply-adds per window sample plus the
+    // epilogue), at least one row
+    double work = 0.0, mine = (double)t.zf_count[c] * (2.0 * native::z64f_win(c) + 40.0);
+    for (int q = 0; q < native::kZ64FineClasses; ++q) work += (double)t.zf_count[q] * (2.0 * native::z64f_win(q) + 40.0);
+    int nr = (int)std::ceil((double)p->native_wgs * (mine / work) / (double)(tiles_f * C));
+    frow[c] = nr < 1 ? 1 : (nr > t.zf_count[c] ? t.zf_count[c] : nr);
+    chunk_total += frow[c];
   }
   // block engine (short-atom bands with wide spectra, double arithmetic): its planes and stat slots come last
   const auto& bt = p->blk[kind];
@@ -954,9 +973,12 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
         chunk_base += sb.nchunk[g];
       }
     }
+    // coarse stage of every level, then the fine launches (heaviest classes first)
+    native::Z64Args zl[native::kZ64Levels];
     for (int g = 0; g < native::kZ64Levels; ++g) {
       if (t.z64_count[g] == 0) continue;
-      native::Z64Args z{};
+      native::Z64Args& z = zl[g];
+      z = native::Z64Args{};
       z.Lf = Lf;
       z.n = n;
       z.log2d = 6 - g;
@@ -967,7 +989,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.bands = t.d_z64 + t.z64_first[g];
       z.X = X;
       z.Hc = static_cast<const cplx<T>*>(t.Hc);
-      z.Z = Z;
+      z.Z = Z + z_off[g] * (size_t)ct;  // (levels side by side: [level][record][band][pad | M | pad])
       z.weights = p->d_z64_w[g];
       z.inv_len = 1.0 / (double)Lf;
       z.two_over_len = (float)(2.0 / (double)Lf);
@@ -978,23 +1000,47 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.time_part = tpart;
       z.part_band = want_band ? part_band : nullptr;
       z.part_stat = want_stat ? part_stat : nullptr;
-      z.nblk = nblk_z;
+      z.nblk = n / native::kZ64Tile;
       z.pb_stride = nbk;
       z.stat_nblk = nblk;
       z.stat_stride = stat_slots;
-      z.chunk_base = chunk_base;
       z.chunk_total = chunk_total;
       z.power_scale = power_scale;
       z.eps = eps;
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
       QI_TRY(native::launch_z64_gather(z, ct, st));
-      QI_TRY(fft_c2c<T>(p->fft, Z, z.M, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
+      QI_TRY(fft_z2z_rows(p->fft, z.Z + native::kZ64Pad, z.M, z.M + 2 * native::kZ64Pad, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
+      QI_TRY(native::launch_z64_pad(z.Z, z.M, (int64_t)z.nbands * ct, st));
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
-      p->prof.begin(st, QI_STAGE_ZOOM);
-      QI_TRY(native::launch_z64_interp(z, zchunk[g], ct, st));
-      p->prof.end(QI_STAGE_ZOOM, st);
+    }
+    p->prof.begin(st, QI_STAGE_ZOOM);
+    for (int c : {6, 5, 4, 3, 0, 1, 2}) {
+      if (t.zf_count[c] == 0) continue;
+      const int g = native::z64f_level(c);
+      native::Z64FineArgs f{};
+      f.z = zl[g];
+      f.z.bands = t.d_z64 + t.zf_first[c];
+      f.z.nbands = t.zf_count[c];
+      f.z.nblk = n / native::kZ64FineWave;
+      f.z.chunk_base = chunk_base;
+      f.cls = c;
+      f.nrow = frow[c];
+      f.lvl_bands = t.z64_count[g];
+      f.lvl_index0 = t.zf_first[c] - t.z64_first[g];
+      f.w = p->d_z64f_w[c];
+      f.lane_ph = t.d_z64_lane_ph ? t.d_z64_lane_ph + (int64_t)t.zf_first[c] * 65 : nullptr;
+      f.wave_ph = t.d_z64_wave_ph;
+      f.debug = p->native_debug;
+      QI_TRY(native::launch_z64_fine(f, ct, st));
+      chunk_base += frow[c];
+    }
+    for (int g = 0; g < native::kZ64Levels; ++g) {
+      if (zchunk[g] == 0) continue;
+      zl[g].chunk_base = chunk_base;
+      QI_TRY(native::launch_z64_interp(zl[g], zchunk[g], ct, st));
       chunk_base += zchunk[g];
     }
+    p->prof.end(QI_STAGE_ZOOM, st);
     if (blocks) {
       native::BlockArgs<T> b{};
       b.n = n;

@@ -45,9 +45,17 @@ __global__ void __launch_bounds__(256) k_z64_gather(Z64Args a) {
       y = mk<double>(x.x * w, x.y * w);
     } else {
       y = cmul(X[(uint32_t)k & mask], a.Hc[bd.src_off + i]);
+      if (a.kind == 0) {
+        // zero-padded kind: panel sample t is full-length sample t + n / 2 - 1.  The odd sample is taken out of the envelope
+        // here -- env'(tau) = env(tau - 1): a phase ramp exp(-2 pi i (i - len / 2) / Lf) on its baseband bins -- so that the
+        // fine stage reads an aligned window (tau = t + n / 2); the carrier keeps its phase at tau - 1
+        double c, s;
+        unit_root_t<double>((uint32_t)(bd.k_len / 2 - (int32_t)i) & mask, a.two_over_len, &c, &s);
+        y = cmul(y, mk<double>(c, s));
+      }
     }
   }
-  a.Z[((int64_t)ch * a.nbands + blockIdx.y) * a.M + q] = y;
+  a.Z[((int64_t)ch * a.nbands + blockIdx.y) * (a.M + 2 * kZ64Pad) + kZ64Pad + q] = y;
 }
 
 // KIND: 0 zero-padded linear correlation (Lf = 2 n, panel sample t = full-length sample t + n / 2 - 1), 1 circular
@@ -75,7 +83,8 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
   const int64_t ch = blockIdx.z, tile = blockIdx.x;
   const int64_t n = a.n;
   constexpr uint32_t TT = (uint32_t)R * kZ64Threads;
-  const uint32_t off = KIND == 0 ? (uint32_t)(n / 2 - 1) : (KIND == 1 ? (uint32_t)(n / 2) : 0u);
+  // (KIND 0: the odd sample of t + n / 2 - 1 sits in the envelope's phase ramp, see k_z64_gather; the carrier below takes it)
+  const uint32_t off = KIND == 2 ? 0u : (uint32_t)(n / 2);
   const uint32_t lmask = (uint32_t)a.Lf - 1u, mmask = (uint32_t)a.M - 1u;
   constexpr uint32_t D = 1u << LOG2D;
   const uint32_t t_first = (uint32_t)tile * TT + (uint32_t)tid;   // this thread's first panel sample
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
   double mx = 0.0, plogp = 0.0;
   for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
     const BandDesc bd = a.bands[jj];
-    const cd* __restrict__ C = a.Z + ((int64_t)ch * a.nbands + jj) * a.M;
+    const cd* __restrict__ C = a.Z + ((int64_t)ch * a.nbands + jj) * (a.M + 2 * kZ64Pad) + kZ64Pad;
     __syncthreads();  // the previous band's readers are done with the window (and with s_red)
     for (int i = tid; i < nwin; i += kZ64Threads) win[i] = C[(m_first + (uint32_t)i) & mmask];
     // carrier: exp(2 pi i k_c tau / Lf) at this thread's first sample, advanced by exp(2 pi i k_c 256 / Lf); the
@@ -109,7 +118,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
     if (KIND != 2) {
       const uint32_t kc = (uint32_t)(bd.k_lo + bd.k_len / 2);
       double c, s;
-      unit_root_t<double>((kc * tau_first) & lmask, a.two_over_len, &c, &s);
+      unit_root_t<double>((kc * (tau_first - (KIND == 0 ? 1u : 0u))) & lmask, a.two_over_len, &c, &s);
       ph = mk<double>(c, s);
       unit_root_t<double>((kc * (uint32_t)kZ64Threads) & lmask, a.two_over_len, &c, &s);
       st = mk<double>(c, s);
@@ -192,6 +201,222 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
   }
 }
 
+// ---- fine stage with wave-uniform windows (see Z64FineArgs in qi_native.hpp) -----------------------------------------
+// Read-only global data through the constant address space: a load whose address is the same for the whole wave then
+// becomes a scalar load (s_load_dword*) -- used for the band descriptors and the wave-uniform carrier factors.  (The
+// WINDOWS were first read this way too: correct, and 20 % slower than k_z64_interp -- the scalar cache is no streaming
+// path: waves waited 60-70 % of their life for s_load data.  They come through a vector register and v_readlane now.)
+template <typename V>
+using z64_cptr = const V __attribute__((address_space(4)))*;
+template <typename V>
+__device__ __forceinline__ z64_cptr<V> as_const(const V* p) {
+  return reinterpret_cast<z64_cptr<V>>(reinterpret_cast<uintptr_t>(p));
+}
+
+#ifdef QI_NATIVE_DEBUG
+#define QI_ZDBG(bit) (a.debug & (bit))
+#else
+#define QI_ZDBG(bit) false
+#endif
+__device__ __forceinline__ double lane_value64(double v, int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// steps whose windows are held in scalar registers together: (GS S + N - 1) coarse samples x 2 registers per part
+constexpr int z64f_group(int cls) {
+  const int s = z64f_span(cls), nt = z64f_ntap(cls);
+  int gs = 8;
+  while (gs > 1 && gs * s + nt - 1 > 24) gs /= 2;
+  return gs;
+}
+
+// One wave: kZ64FineWave consecutive panel samples of the bands row, row + nrow, ... of class CLS.  Output sample
+// t = t_wave + 64 s + lane is the coarse-grid position (tau >> LOG2D) + (tau & (D - 1)) / D, tau = t + off (off = n / 2 for
+// the Gabor kinds: crop / roll; the zero-padded kind's odd sample is in the envelope, k_z64_gather); its N taps are window
+// samples s S + q .. s S + q + N - 1 of the wave's window, q = lane >> LOG2D, which starts N / 2 - 1 coarse samples before
+// the wave's first one.  A band's coarse array is [kZ64Pad | M | kZ64Pad] samples, the pads holding the other end's samples
+// (k_z64_pad): a wave's window is always a run of consecutive samples -- lane i loads sample m_wave + i (16 bytes, a band
+// ahead), and the lanes' arithmetic takes sample e from lane e through scalar registers (v_readlane).
+template <int KIND, int CLS, bool COEF>
+__device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int row, const double (*ltab)[2], double* __restrict__ colv) {
+  constexpr int LEVEL = z64f_level(CLS), LOG2D = 6 - LEVEL, S = 1 << LEVEL, N = z64f_ntap(CLS), WL = N + S - 1;
+  constexpr int STEPS = kZ64FineSteps, GS = z64f_group(CLS), WIN = GS * S + N - 1;
+  static_assert(N / 2 <= kZ64Pad && STEPS % GS == 0, "window reach / group size");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  const int64_t ch = blockIdx.z, n = a.z.n;
+  const uint32_t slot = blockIdx.x * (kZ64Threads / kWave) + (uint32_t)wv;  // wave along time = partial slot of its bands
+  const uint32_t t_wave = slot * (uint32_t)kZ64FineWave;
+  const uint32_t tau_wave = (t_wave + (KIND == 2 ? 0u : (uint32_t)(n / 2))) & ((uint32_t)a.z.Lf - 1u);
+  const int32_t m_wave = (int32_t)(tau_wave >> LOG2D) - (N / 2 - 1);  // first window sample of the wave (>= -kZ64Pad)
+  double w[WL];
+#pragma unroll
+  for (int j = 0; j < WL; ++j) w[j] = a.w[j * kWave + lane];
+  // per-time power sums of the wave's samples over its bands: in LDS (8 KB per wave), not in 2 x 16 registers per lane
+  double* __restrict__ col0 = colv + wv * kZ64FineWave + lane;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) col0[s * kWave] = 0.0;
+  double mx = 0.0, plogp = 0.0;
+  const uint32_t tt0 = t_wave + (uint32_t)lane;
+  const int64_t zstride = a.z.M + 2 * kZ64Pad;
+  constexpr int NEED = STEPS * S + N - 1;  // coarse samples one wave needs per band
+  constexpr bool TWO = NEED > kWave;       // ... in two registers of its lanes
+  static_assert(NEED <= 2 * kWave, "the window of one wave must fit two registers of its lanes");
+  cd smp_next = mk<double>(0.0, 0.0), smq_next = smp_next;
+  if (row < a.z.nbands) {
+    const cd* __restrict__ Cn = a.z.Z + ((int64_t)ch * a.lvl_bands + a.lvl_index0 + row) * zstride + kZ64Pad + m_wave;
+    smp_next = Cn[lane < NEED ? lane : NEED - 1];
+    if (TWO) smq_next = Cn[kWave + (lane < NEED - kWave ? lane : NEED - kWave - 1)];
+  }
+  for (int jj = row; jj < a.z.nbands; jj += a.nrow) {
+    const auto bd = as_const(a.z.bands + jj);
+    const int32_t out_band = bd->out_band, add_row = bd->add_row;
+    // lane i holds coarse sample m_wave + i of the band (requested a band ahead); wave-step s interpolates from samples
+    // s S .. s S + N + S - 2 of that window, handed to the lanes' arithmetic through scalar registers (v_readlane)
+    const cd smp = smp_next, smq = smq_next;
+    if (jj + a.nrow < a.z.nbands) {
+      const cd* __restrict__ Cn = a.z.Z + ((int64_t)ch * a.lvl_bands + a.lvl_index0 + jj + a.nrow) * zstride + kZ64Pad + m_wave;
+      smp_next = Cn[lane < NEED ? lane : NEED - 1];
+      if (TWO) smq_next = Cn[kWave + (lane < NEED - kWave ? lane : NEED - kWave - 1)];
+    }
+    cd ph = mk<double>(1.0, 0.0), st = ph;
+    if (KIND != 2) {
+      // carrier exp(2 pi i k_c (tau - e) / Lf), tau = tau_wave + 64 s + lane: the wave's factor (tau_wave is a multiple of
+      // kZ64FineWave: exact phase, table) x the lane's (table) at step 0, advanced by the exact step of 64 samples
+      const uint32_t kc = (uint32_t)(bd->k_lo + bd->k_len / 2);
+      const auto lp = a.lane_ph + (int64_t)jj * 65;
+      const auto wp = as_const(reinterpret_cast<const double*>(a.wave_ph)) +
+                      2 * ((kc * (tau_wave / (uint32_t)kZ64FineWave)) & (uint32_t)(a.z.Lf / kZ64FineWave - 1));
+      const auto sp = as_const(reinterpret_cast<const double*>(lp + 64));
+      ph = cmul_rn(lp[lane], mk<double>(wp[0], wp[1]));
+      st = mk<double>(sp[0], sp[1]);
+    }
+    const int64_t orow = ((int64_t)ch * a.z.panel_bands + out_band) * n;
+    // split band (add_row): only the tapered part of its atom -- the samples go to split_part and count for nothing here
+    const bool part = add_row != 0;
+    cd* __restrict__ coef_row = part ? a.z.split_part + ((int64_t)ch * a.z.split_rows + (add_row - 1)) * n
+                                     : (COEF ? a.z.coef + orow : nullptr);
+    double* __restrict__ bits_row = a.z.bits && !part ? a.z.bits + orow : nullptr;
+    const double pscale = part ? 0.0 : a.z.power_scale;
+    double rowacc = 0.0, pl = 0.0;
+#pragma unroll
+    for (int g = 0; g < STEPS / GS; ++g) {
+      double zr[GS], zi[GS];
+      // the window of one group and one part at a time (2 (GS S + N - 1) scalar registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int part_i = 0; part_i < 2; ++part_i) {
+        double sx[WIN];
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+          const int e = g * GS * S + i;  // window sample (compile-time): lane e of smp, or lane e - 64 of smq
+          sx[i] = e < kWave ? lane_value64(part_i == 0 ? smp.x : smp.y, e) : lane_value64(part_i == 0 ? smq.x : smq.y, e - kWave);
+        }
+#pragma unroll
+        for (int s = 0; s < GS; ++s) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < WL; ++j)
+            if (j == 0 || !QI_ZDBG(2)) acc = fma(w[j], sx[s * S + j], acc);
+          if (part_i == 0) zr[s] = acc;
+          else zi[s] = acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        cd z = mk<double>(zr[s], zi[s]);
+        if (KIND != 2 && !QI_ZDBG(16)) {
+          z = cmul_rn(z, ph);
+          ph = cmul_rn(ph, st);
+          zr[s] = z.x;
+          zi[s] = z.y;
+        }
+        const double p = mul_rn(pscale, norm2(z.x, z.y));
+        if (!QI_ZDBG(8)) col0[(g * GS + s) * kWave] += p;
+        rowacc += p;
+        mx = max_t(mx, p);
+        if (!QI_ZDBG(4)) pl += plog2p_flat(p, ltab);
+        if (s & 1) {  // two outputs in flight: more only cost registers (the fence pins the running sums: without it every
+          // power of the band stays in registers until a deferred chain of maxima at the end of the loop)
+          asm volatile("" : "+v"(mx), "+v"(pl), "+v"(rowacc));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // (the stores of a group behind ONE wave-uniform branch each, not one per output)
+      if ((COEF || part) && !QI_ZDBG(1)) {
+#pragma unroll
+        for (int s = 0; s < GS; ++s) stream_store(coef_row + tt0 + (uint32_t)(kWave * (g * GS + s)), mk<double>(zr[s], zi[s]));
+      }
+      if (bits_row) {
+#pragma unroll
+        for (int s = 0; s < GS; ++s)
+          bits_row[tt0 + (uint32_t)(kWave * (g * GS + s))] = log2_t(sqrt_t(norm2(zr[s], zi[s])) + a.z.eps);
+      }
+    }
+    plogp += pl;
+    if (a.z.part_band && !part) {
+      const double rs = wave_sum(rowacc);
+      if (lane == 0) a.z.part_band[((int64_t)ch * a.z.panel_bands + out_band) * a.z.pb_stride + slot] = rs;
+    }
+  }
+  double tot = 0.0;
+  double* __restrict__ time_row =
+      a.z.time_part ? a.z.time_part + ((int64_t)ch * a.z.chunk_total + a.z.chunk_base + row) * n : nullptr;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const double v = col0[s * kWave];
+    tot += v;
+    if (time_row) time_row[tt0 + (uint32_t)(kWave * s)] = v;
+  }
+  if (a.z.part_stat) {
+    const double r0 = wave_max(mx), r1 = wave_sum(tot), r2 = wave_sum(plogp);
+    if (lane == 0) {
+      double* o = a.z.part_stat + ((int64_t)ch * a.z.stat_stride + (int64_t)(a.z.chunk_base + row) * a.z.stat_nblk + slot) * 3;
+      o[0] = r0;
+      o[1] = r1;
+      o[2] = r2;
+    }
+  }
+}
+
+// one launch per class: blockIdx.y is the row (chunk of the class's band list); registers as the class needs them
+template <int KIND, int CLS, bool COEF>
+__global__ void __launch_bounds__(kZ64Threads, z64f_ntap(CLS) >= 16 ? 3 : 4) k_z64_fine(Z64FineArgs a) {
+  __shared__ double ltab[128][2];  // log2 table of the entropy sums (see log2_pos)
+  __shared__ double colv[(kZ64Threads / kWave) * kZ64FineWave];
+  const int tid = threadIdx.x;
+  if (tid < 128) {
+    ltab[tid][0] = kLog2Tab[tid][0];
+    ltab[tid][1] = kLog2Tab[tid][1];
+  }
+  __syncthreads();
+  z64_fine_class<KIND, CLS, COEF>(a, blockIdx.y, ltab, colv);
+}
+
+// the pads of the coarse arrays: [kZ64Pad | M | kZ64Pad] per band and record, pads = the samples of the other end
+__global__ void __launch_bounds__(64) k_z64_pad(cd* __restrict__ Z, int64_t M) {
+  cd* z = Z + (int64_t)blockIdx.x * (M + 2 * kZ64Pad);
+  const int i = threadIdx.x;
+  if (i < kZ64Pad) z[i] = z[M + i];                      // front pad <- last samples
+  else if (i < 2 * kZ64Pad) z[M + i] = z[i];             // back pad <- first samples (i - kZ64Pad + kZ64Pad)
+}
+
+template <int KIND, bool COEF>
+void launch_fine_cls(const Z64FineArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.cls) {
+    case 0: k_z64_fine<KIND, 0, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    case 1: k_z64_fine<KIND, 1, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    case 2: k_z64_fine<KIND, 2, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    case 3: k_z64_fine<KIND, 3, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    case 4: k_z64_fine<KIND, 4, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    case 5: k_z64_fine<KIND, 5, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+    default: k_z64_fine<KIND, 6, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+  }
+}
+
 template <int KIND>
 int launch_interp_v(const Z64Args& a, dim3 grid, hipStream_t st) {
   switch (a.log2d) {
@@ -216,6 +441,13 @@ int launch_z64_gather(const Z64Args& a, int64_t n_channels, hipStream_t st) {
   return QI_OK;
 }
 
+int launch_z64_pad(cplx<double>* Z, int64_t M, int64_t rows, hipStream_t st) {
+  if (rows <= 0) return QI_OK;
+  k_z64_pad<<<(unsigned)rows, 64, 0, st>>>(Z, M);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
 int launch_z64_interp(const Z64Args& a, int nchunk, int64_t n_channels, hipStream_t st) {
   if (a.nbands <= 0) return QI_OK;
   const int64_t TT = a.n / a.nblk;
@@ -225,6 +457,71 @@ int launch_z64_interp(const Z64Args& a, int nchunk, int64_t n_channels, hipStrea
   }
   dim3 grid((unsigned)a.nblk, (unsigned)nchunk, (unsigned)n_channels);
   return a.kind == 0 ? launch_interp_v<0>(a, grid, st) : (a.kind == 1 ? launch_interp_v<1>(a, grid, st) : launch_interp_v<2>(a, grid, st));
+}
+
+
+int launch_z64_fine(const Z64FineArgs& a, int64_t n_channels, hipStream_t st) {
+  if (a.nrow <= 0 || a.z.nbands <= 0) return QI_OK;
+  const int64_t per_wg = (int64_t)kZ64FineWave * (kZ64Threads / kWave);
+  if (a.z.n % per_wg != 0 || a.z.nblk * kZ64FineWave != a.z.n || (a.z.n / 2) % kZ64FineWave != 0 || (a.z.Lf & (a.z.Lf - 1)) != 0 ||
+      a.cls < 0 || a.cls >= kZ64FineClasses || a.z.M != (a.z.Lf >> (6 - z64f_level(a.cls)))) {
+    set_error("float64 zoom: a record of %lld samples / class %d not supported", (long long)a.z.n, a.cls);
+    return QI_ERR_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)(a.z.n / per_wg), (unsigned)a.nrow, (unsigned)n_channels);
+  const bool coef = a.z.coef != nullptr;
+  if (a.z.kind == 0) coef ? launch_fine_cls<0, true>(a, grid, st) : launch_fine_cls<0, false>(a, grid, st);
+  else if (a.z.kind == 1) coef ? launch_fine_cls<1, true>(a, grid, st) : launch_fine_cls<1, false>(a, grid, st);
+  else coef ? launch_fine_cls<2, true>(a, grid, st) : launch_fine_cls<2, false>(a, grid, st);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+// N taps (nodes -N/2 + 1 .. N/2) of the interpolator to the fraction x in [0, 1) that is exact for the tones at the N / 2
+// Chebyshev nodes of the band [-band, band] (radians per coarse sample); solved in long double
+static void z64_taps(int N, long double band, long double x, long double* out) {
+  const int half = N / 2;
+  const long double pi = 3.14159265358979323846264338327950288L;
+  long double M[16][17];
+  for (int k = 0; k < half; ++k) {
+    const long double om = band * std::cos((long double)(2 * k + 1) * pi / (long double)(2 * N));
+    for (int c = 0; c < N; ++c) {
+      const long double node = (long double)(c - half + 1);
+      M[k][c] = std::cos(om * node);
+      M[half + k][c] = std::sin(om * node);
+    }
+    M[k][N] = std::cos(om * x);
+    M[half + k][N] = std::sin(om * x);
+  }
+  for (int i = 0; i < N; ++i) {  // Gauss-Jordan with partial pivoting
+    int piv = i;
+    for (int r = i + 1; r < N; ++r)
+      if (std::fabs((double)M[r][i]) > std::fabs((double)M[piv][i])) piv = r;
+    if (piv != i)
+      for (int c = 0; c <= N; ++c) std::swap(M[i][c], M[piv][c]);
+    const long double d = M[i][i];
+    for (int c = 0; c <= N; ++c) M[i][c] /= d;
+    for (int r = 0; r < N; ++r) {
+      if (r == i) continue;
+      const long double f = M[r][i];
+      if (f == 0.0L) continue;
+      for (int c = 0; c <= N; ++c) M[r][c] -= f * M[i][c];
+    }
+  }
+  for (int c = 0; c < N; ++c) out[c] = M[c][N];
+}
+
+// weights of the lanes for class `cls`, layout [window sample j][lane]: lane sits q = lane / D coarse intervals after the
+// window's reference sample (index N / 2 - 1) at the fraction x = (lane mod D) / D; its N taps are window samples q .. q + N - 1
+void z64_fine_weights(int cls, double* w) {
+  const int N = z64f_ntap(cls), WL = z64f_win(cls), log2d = 6 - z64f_level(cls), D = 1 << log2d;
+  const long double band = 3.14159265358979323846264338327950288L / (long double)z64f_oversampling(cls);
+  for (int lane = 0; lane < kWave; ++lane) {
+    const int q = lane >> log2d;
+    long double t[16];
+    z64_taps(N, band, (long double)(lane & (D - 1)) / (long double)D, t);
+    for (int j = 0; j < WL; ++j) w[j * kWave + lane] = (j >= q && j - q < N) ? (double)t[j - q] : 0.0;
+  }
 }
 
 // weights[phase][tap] of coarse step D = 1 << log2d: the 16-tap interpolator at x = phase / D that is exact for the

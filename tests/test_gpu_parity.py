@@ -662,7 +662,8 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
     knobs = ("QI_NATIVE_SPLIT", "QI_NATIVE_SPLIT64", "QI_NATIVE_Z64", "QI_NATIVE_BLOCK64")
     if not any(k in os.environ for k in knobs):
         assert plan.stage_bands("pass2")[0] == 0 and plan.stage_bands("pass2")[2] == 0
-        assert plan.stage_bands("block")[0] >= 14 + 20 and plan.stage_bands("block")[2] >= 20
+        assert plan.stage_bands("block")[0] >= 20 and plan.stage_bands("block")[2] >= 20
+        assert plan.stage_bands("block")[0] + plan.stage_bands("zoom")[0] == nb  # (the 14 split bands count with the zoom engine)
     full = plan.cwt_stx(x, coef=True, reductions=True)
     lean = plan.cwt_stx(x, coef=False, reductions=True)
     torch.cuda.synchronize()
@@ -708,8 +709,12 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
         g = golden("large_n1048576_o12_f64.npz")
         assert np.max(np.abs(recs[0][:: n // 4096] - g["sig_samples"])) == 0.0 and np.array_equal(f, g["f_o12"])
         assert len(g["rows_o12"]) == nb
+        # (entropy: the reference adds eps64 to every pdf value inside its logarithm (tfr_info.py:203-228), which lowers H by
+        # sum pdf log2(1 + eps / pdf) <= D eps / ln 2 = 5.6e-8 bits for the D = 167 x 2^20 points of this panel; the fused
+        # H = log2 S - sum(P log2 P) / S has no such term)
+        ent_tol = 1.05 * nb * n * float(orc.EPS64) / np.log(2.0) + 1e-9
         for a, name in zip(full, ("cwt", "stx")):
-            check_digest(a, g, name, order, dict(tol, bits_floor=1e-3, row=5e-9, ent=5e-8), g["rows_o12"])
+            check_digest(a, g, name, order, dict(tol, bits_floor=1e-3, row=5e-9, ent=ent_tol), g["rows_o12"])
     del full, lean
     plan.close()
 

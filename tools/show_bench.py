@@ -8,8 +8,10 @@ def show(x, ind=0):
     pad = " " * ind
     r = x["roofline"]
     print(f"{pad}{x['config']['workload'][:60]}")
-    print(f"{pad}  value {x['value']:.0f}  ms/step {x['ms_per_step']}  step_frac {x['step_roofline']['frac']}")
-    print(f"{pad}  dominant {r['kernel']} frac {r['frac']} launch_ms {r['launch_ms']}")
+    print(f"{pad}  value {x['value']:.0f}  ms/step {x['ms_per_step']}  step_frac {x['step_roofline'].get('frac')}")
+    print(f"{pad}  dominant {r['kernel']} frac {r['frac']} launch_ms {r.get('launch_ms')}")
+    if "stage_ms_per_step" not in x["step_roofline"]:
+        return
     for k, v in x.get("stage_rooflines", {}).items():
         print(f"{pad}  stage {k} frac {v['frac']} launch_ms {v['launch_ms']} x{v['launches_per_step']}")
     print(f"{pad}  stages {x['step_roofline']['stage_ms_per_step']}")
@@ -26,7 +28,7 @@ for f in sys.argv[1:]:
         d = json.loads(ln)
         print("==", f)
         show(d)
-        for k in ("configs2", "f64", "configs1_per_gpu"):
+        for k in ("configs2", "f64", "configs4", "configs1_per_gpu"):
             if k in d:
                 print(" ", k)
                 show(d[k], 4)
