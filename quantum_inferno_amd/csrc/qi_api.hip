@@ -195,6 +195,8 @@ int qi_plan_destroy(qi_plan* p) {
     if (w) (void)hipFree(w);
   for (auto* w : p->d_z64f_w)
     if (w) (void)hipFree(w);
+  if (p->d_demod_t1) (void)hipFree(p->d_demod_t1);
+  if (p->d_demod_t2) (void)hipFree(p->d_demod_t2);
   for (auto& wc : p->d_zoom_w)
     for (auto* w : wc)
       if (w) (void)hipFree(w);

@@ -286,6 +286,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
                                             cplx<T> w, int edge_piece = 0) {
   static_assert(!EDGE || !DEMOD, "split bands belong to the styx table");
   constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
+  constexpr bool F64 = sizeof(T) == 8;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // the column this thread owns
   const int64_t blk = blk_i, ch = blockIdx.z;
@@ -324,8 +325,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     } else {
       if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
     }
-    cplx<T> v[16];
-    constexpr bool F64 = sizeof(T) == 8;  // float64 tables hold analytic bands only, none of them `narrow`
+    cplx<T> v[16];  // (F64: float64 tables hold analytic bands only, none of them `narrow`)
     if (!EDGE && !F64 && bd.narrow == 1) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
       // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
@@ -434,13 +434,29 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     }
 
     cplx<T> ph = mk<T>(T(1), T(0));
-    if (DEMOD) {
+    if (DEMOD && !F64) {
       // exp(-2 pi i idx t / n) at this thread's first output; idx * t mod n is exact in 32-bit wraparound
       const uint32_t m = (0u - (uint32_t)bd.shift * tb0) & (uint32_t)(n - 1);
       double s, c;
       unit_root_t<T>(m, a.two_over_n, &c, &s);
       ph = mk<T>((T)c, (T)s);
     }
+    if constexpr (DEMOD && F64) {
+      // float64: exp(-2 pi i idx t / n) of output i (t = V blk + col + 256 i) as a product of three exact-phase factors from
+      // tables -- no double-precision sincospi per band and thread, and no phasor state carried through the epilogue (seed,
+      // running power and two steps were 16 registers that did not fit beside the block spectrum: 270-390 bytes of scratch
+      // per lane in round 3): the block's and the column's factors (two table entries each, exp(-2 pi i m / n) =
+      // t1[m >> 10] t2[m & 1023]) give `ph` here, the 256 i samples' factor is a wave-uniform table entry per output.
+      const uint32_t nm = (uint32_t)(n - 1);
+      const uint32_t mA = ((uint32_t)bd.shift * (uint32_t)(blk * V)) & nm;  // (the same for the whole workgroup; idx t mod n
+      const uint32_t mB = ((uint32_t)bd.shift * (uint32_t)col) & nm;            // is exact in 32-bit wraparound)
+      const auto t1s = as_const(reinterpret_cast<const T*>(a.demod_t1) + 2 * (mA >> 10));
+      const auto t2s = as_const(reinterpret_cast<const T*>(a.demod_t2) + 2 * (mA & 1023u));
+      const cplx<T> fa = cmul_rn(mk<T>(t1s[0], t1s[1]), mk<T>(t2s[0], t2s[1]));
+      const cplx<T> fb = cmul_rn(a.demod_t1[mB >> 10], a.demod_t2[mB & 1023u]);
+      ph = cmul_rn(fa, fb);
+    }
+    [[maybe_unused]] const auto demod_pow = as_const(reinterpret_cast<const T*>(a.demod_pow) + 32 * (int64_t)(band_first + jj));
     const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
     char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
     char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
@@ -448,7 +464,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     T rowacc = T(0), pl = T(0);
     // demodulation phasor of output i: ph * r^i (r: 256 samples); every fourth one from the exact power r^4 (at most
     // three roundings), the ones between advance by r -- held one at a time, not as an array of NOUT
-    const cplx<T> R1 = mk<T>((T)bd.rot[0], (T)bd.rot[1]), R4 = mk<T>((T)bd.rot[4], (T)bd.rot[5]);
+    [[maybe_unused]] const cplx<T> R1 = mk<T>((T)bd.rot[0], (T)bd.rot[1]), R4 = mk<T>((T)bd.rot[4], (T)bd.rot[5]);
     uint32_t tp = tb_pair;
     asm volatile("" : "+v"(tp));  // keep the band-invariant addresses out of the loop-invariant hoisting
     // Two outputs at a time: demodulate, bring the two ADJACENT samples of a pair into one lane (half_swap), then
@@ -463,7 +479,9 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           z[h] = v[brev(i + h + WQ, 4)];
-          if (DEMOD && !QI_BDBG(32)) {
+          if constexpr (DEMOD && F64) {
+            if (!QI_BDBG(32)) z[h] = cmul_rn(z[h], cmul_rn(ph, mk<T>(demod_pow[2 * (i + h)], demod_pow[2 * (i + h) + 1])));
+          } else if (DEMOD && !QI_BDBG(32)) {
             if (i + h > 0) {
               if (((i + h) & 3) == 0) {
                 seed = cmul_rn(seed, R4);
@@ -1230,7 +1248,10 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
 // middle of the record, which see both pieces, go band by band through edge_item.  A kernel of its own (k_block_edge):
 // inside k_block / k_block_dual the band loop costs every variant its register budget (0 -> 236-396 bytes of scratch per
 // lane, measured).
-template <typename T, int WQ, bool COEF, bool BITS>
+// PATH: 0 both kinds of block in one kernel (float32); float64 compiles them apart -- the two-piece blocks' band-by-band
+// path (1) costs the one-piece path (2) its register allocation when they share a kernel (500-600 bytes of scratch per lane
+// in round 3): a block of the other kind is left to the other kernel's launch.
+template <typename T, int WQ, bool COEF, bool BITS, int PATH = 0>
 __device__ __forceinline__ void edge_block_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
                                                 const cplx<T>* __restrict__ tw256, double (*s_red)[kBlkThreads / kWave],
                                                 cplx<T> w) {
@@ -1241,13 +1262,16 @@ __device__ __forceinline__ void edge_block_item(const BlockArgs<T>& a, const Blo
   const int64_t in_p[2] = {t0 + (n / 2 - W), t0 - (n / 2 - W)};
   const bool has_p[2] = {!(in_p[0] >= n || in_p[0] + kBlk <= 0), !(in_p[1] >= n || in_p[1] + kBlk <= 0)};
   if (has_p[0] && has_p[1]) {  // (the same for every thread of the workgroup)
-    for (int32_t q = 0; q < it.band_count; ++q) {
-      const BlockItem one{it.wq, it.block, it.band_first + q, 0, it.plane, it.stat_slot};
-      if (q > 0) __syncthreads();  // the previous band's statistics have left the exchange buffer
-      edge_item<T, WQ, COEF, BITS>(a, one, buf, tw256, w, q > 0);
+    if constexpr (PATH != 2) {
+      for (int32_t q = 0; q < it.band_count; ++q) {
+        const BlockItem one{it.wq, it.block, it.band_first + q, 0, it.plane, it.stat_slot};
+        if (q > 0) __syncthreads();  // the previous band's statistics have left the exchange buffer
+        edge_item<T, WQ, COEF, BITS>(a, one, buf, tw256, w, q > 0);
+      }
     }
     return;
   }
+  if constexpr (PATH == 1) return;
   const int piece = has_p[0] ? 0 : 1;
   const T* __restrict__ sig = a.sig + (int64_t)blockIdx.z * n;
   cplx<T> S[16];
@@ -1372,8 +1396,9 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a)
   }
 }
 
-// the split bands of a float64 styx table: one edge item per block (edge_block_item), always a launch of its own
-template <bool COEF, bool BITS>
+// the split bands of a float64 styx table: one edge item per block (edge_block_item), always a launch of its own (PATH 2:
+// the blocks that see one piece of the record; PATH 1: a second, small launch for the blocks around the middle that see both)
+template <bool COEF, bool BITS, int PATH>
 __global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<double> a, const BlockItem* __restrict__ items) {
   extern __shared__ __attribute__((aligned(16))) char smem64[];
   double2* buf = reinterpret_cast<double2*>(smem64);
@@ -1388,9 +1413,9 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<doubl
   const double2 w = make_double2(c, s);
   const BlockItem it = items[blockIdx.x];
   switch (-it.wq) {
-    case 1: edge_block_item<double, 1, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
-    case 2: edge_block_item<double, 2, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
-    default: edge_block_item<double, 4, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
+    case 1: edge_block_item<double, 1, COEF, BITS, PATH>(a, it, buf, tw256, s_red, w); break;
+    case 2: edge_block_item<double, 2, COEF, BITS, PATH>(a, it, buf, tw256, s_red, w); break;
+    default: edge_block_item<double, 4, COEF, BITS, PATH>(a, it, buf, tw256, s_red, w); break;
   }
 }
 
@@ -1754,7 +1779,7 @@ static int launch_block_edge(const BlockArgs<float>& a, const BlockItem* items, 
 }
 
 template <>
-int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st) {
+int launch_block<float>(const BlockArgs<float>& a, int demod, int64_t n_channels, hipStream_t st, hipStream_t, hipEvent_t, hipEvent_t) {
   if (a.nitems + a.nedge_items <= 0) return QI_OK;
   if (a.nlong > 0) QI_TRY(launch_block_long(a, demod, a.items, a.nlong, n_channels, st));
   BlockArgs<float> rest = a;
@@ -1787,32 +1812,65 @@ static int launch_block64_v(const BlockArgs<double>& a, dim3 grid, hipStream_t s
   return QI_OK;
 }
 template <>
-int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channels, hipStream_t st) {
+int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channels, hipStream_t st, hipStream_t side, hipEvent_t fork,
+                         hipEvent_t join) {
   if (a.nitems + a.nedge_items <= 0) return QI_OK;
-  if (a.nlong > 0 || (a.nedge_items > 0 && !a.edge_merged)) {
+  if (a.nlong > 0 || (a.nedge_items > 0 && (!a.edge_merged || a.edge_wq < 1 || a.edge_wq > 4))) {
     set_error("block engine: float64 tables have no long blocks, and their split bands one edge item per block");
     return QI_ERR_STATE;
+  }
+  const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
+  const BlockItem* items = a.items + a.nitems;
+  // the blocks around the middle of the record see both far pieces: items [mid_lo, mid_hi] of the (block-ordered) edge list,
+  // a small launch of the band-by-band kernel; every other block goes through the one-piece kernel
+  int64_t mid_lo = -1, mid_hi = -2;
+  if (a.nedge_items > 0) {
+    const int64_t W = 256 * (int64_t)a.edge_wq, V = kBlk - 2 * W;
+    for (int64_t b = 0; b < a.nedge_items; ++b) {
+      const int64_t t0 = b * V - W, p0 = t0 + (a.n / 2 - W), p1 = t0 - (a.n / 2 - W);
+      if (!(p0 >= a.n || p0 + kBlk <= 0) && !(p1 >= a.n || p1 + kBlk <= 0)) {
+        if (mid_lo < 0) mid_lo = b;
+        mid_hi = b;
+      }
+    }
+  }
+#define QI_E64(C, B, PATH, GRID, ITEMS, STREAM)                                                         \
+  do {                                                                                                  \
+    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_block64_edge<C, B, PATH>), kBlk64Lds));   \
+    k_block64_edge<C, B, PATH><<<GRID, kBlkThreads, kBlk64Lds, STREAM>>>(a, ITEMS);                     \
+  } while (0)
+#define QI_E64_ALL(PATH, GRID, ITEMS, STREAM)                          \
+  do {                                                                 \
+    if (coef && bits) QI_E64(true, true, PATH, GRID, ITEMS, STREAM);   \
+    else if (coef) QI_E64(true, false, PATH, GRID, ITEMS, STREAM);     \
+    else if (bits) QI_E64(false, true, PATH, GRID, ITEMS, STREAM);     \
+    else QI_E64(false, false, PATH, GRID, ITEMS, STREAM);              \
+  } while (0)
+  const bool mids = mid_hi >= mid_lo;
+  const bool beside = mids && side && fork && join && a.nitems > 0;  // the two-piece items beside the band items
+  if (mids) {
+    const dim3 grid_mid((unsigned)(mid_hi - mid_lo + 1), 1, (unsigned)n_channels);
+    hipStream_t ms = beside ? side : st;
+    if (beside) {
+      QI_HIP(hipEventRecord(fork, st));
+      QI_HIP(hipStreamWaitEvent(side, fork, 0));
+    }
+    QI_E64_ALL(1, grid_mid, items + mid_lo, ms);
+    QI_LAUNCH_CHECK();
+    if (beside) QI_HIP(hipEventRecord(join, side));
   }
   if (a.nitems > 0) {
     dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
     QI_TRY((demod ? launch_block64_v<true>(a, grid, st) : launch_block64_v<false>(a, grid, st)));
   }
   if (a.nedge_items > 0) {
-    const bool coef = a.coef != nullptr, bits = a.bits != nullptr;
     dim3 grid((unsigned)a.nedge_items, 1, (unsigned)n_channels);
-    const BlockItem* items = a.items + a.nitems;
-#define QI_E64(C, B)                                                                                 \
-  do {                                                                                               \
-    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_block64_edge<C, B>), kBlk64Lds));      \
-    k_block64_edge<C, B><<<grid, kBlkThreads, kBlk64Lds, st>>>(a, items);                            \
-  } while (0)
-    if (coef && bits) QI_E64(true, true);
-    else if (coef) QI_E64(true, false);
-    else if (bits) QI_E64(false, true);
-    else QI_E64(false, false);
-#undef QI_E64
+    QI_E64_ALL(2, grid, items, st);
     QI_LAUNCH_CHECK();
   }
+  if (beside) QI_HIP(hipStreamWaitEvent(st, join, 0));
+#undef QI_E64_ALL
+#undef QI_E64
   return QI_OK;
 }
 

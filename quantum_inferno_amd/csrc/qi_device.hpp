@@ -83,6 +83,16 @@ __device__ __forceinline__ T wave_max(T v) {
 }
 #endif
 
+// Read-only global data through the constant address space: a load whose address is the same for the whole wave becomes a
+// scalar load (s_load_dword*): its result lives in scalar registers and is an operand of the lanes' arithmetic.  For small
+// wave-uniform tables only -- the scalar cache is no streaming path.
+template <typename V>
+using qi_cptr = const V __attribute__((address_space(4)))*;
+template <typename V>
+__device__ __forceinline__ qi_cptr<V> as_const(const V* p) {
+  return reinterpret_cast<qi_cptr<V>>(reinterpret_cast<uintptr_t>(p));
+}
+
 // streaming stores of panel data that is never read back by this launch (nontemporal: no allocation in the caches)
 typedef float qi_f2 __attribute__((ext_vector_type(2)));
 typedef float qi_f4 __attribute__((ext_vector_type(4)));

@@ -285,6 +285,7 @@ struct qi_plan {
     // and fewer per-time planes, for batches that fill the chip anyway.
     struct ItemList {
       void* d_bands = nullptr;  // native::BlockBandT<T>[]: all reach groups, group by group (cut 1 keeps some bands on long blocks)
+      void* d_demod_pow = nullptr;  // float64 Stockwell tables: [bands][16] demodulation factors (BlockArgs::demod_pow)
       std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
       native::BlockItem* d_items = nullptr;
       int32_t nitems = 0, nplanes = 0;
@@ -298,6 +299,7 @@ struct qi_plan {
       if (bank) (void)hipFree(bank);
       for (auto& v : var) {
         if (v.d_bands) (void)hipFree(v.d_bands);
+        if (v.d_demod_pow) (void)hipFree(v.d_demod_pow);
         if (v.d_items) (void)hipFree(v.d_items);
       }
       *this = BlockTable();
@@ -334,6 +336,8 @@ struct qi_plan {
   int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
   double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level
   double* d_z64f_w[native::kZ64FineClasses] = {};  // lane weights per class of the fine kernel
+  double2* d_demod_t1 = nullptr;  // float64 block engine, Stockwell demodulation: exp(-2 pi i 1024 j / n), j < n / 1024
+  double2* d_demod_t2 = nullptr;  // ... exp(-2 pi i j / n), j < 1024
   int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
   int native_f64 = 1;      // float64 plans run on the native engines in double arithmetic (2^20 / 2^21-point transforms)
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers

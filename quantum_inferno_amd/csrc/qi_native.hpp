@@ -152,6 +152,7 @@ struct BlockArgs {
   int32_t nitems, panel_bands;
   int32_t nedge_items, nsplit;  // edge items of the split bands, after the nitems band items
   int32_t edge_merged;          // the edge items cover all split bands of a block each and run as a launch of their own
+  int32_t edge_wq;              // reach group of the edge pieces (taps within 256 * edge_wq samples)
   int32_t nlong;                // of the nitems band items, the first nlong are long-block items (a launch of their own)
   const int32_t* edge_band;     // [nsplit] device: panel row of each split band
   const cplx<T>* edge_bank;     // [nsplit][2][kBlk]
@@ -160,6 +161,11 @@ struct BlockArgs {
   const BlockBandT<T>* bands;  // device, all reach groups
   const cplx<T>* bank;     // [rows][kBlk], scaled by 1 / kBlk
   const float* lz_w;       // local zoom: [2][8][kBlkLzTaps] interpolation weights for D = 4 and D = 8 (lz_weights)
+  // float64 Stockwell tables: demodulation factors from tables (see block_bands): per band of `bands` the sixteen
+  // exp(-2 pi i idx 256 i / n), and exp(-2 pi i m / n) = demod_t1[m >> 10] demod_t2[m & 1023]
+  const cplx<T>* demod_pow;  // [bands][16]
+  const cplx<T>* demod_t1;   // [n / 1024] exp(-2 pi i 1024 j / n)
+  const cplx<T>* demod_t2;   // [1024] exp(-2 pi i j / n)
   const T* sig;            // [C][n]
   cplx<T>* coef;
   T* bits;
@@ -174,8 +180,11 @@ struct BlockArgs {
   unsigned long long* stamps;  // diagnostic builds only (-DQI_NATIVE_STAMPS): [workgroup][8] phase cycles
 };
 int block_valid(int wq);  // outputs per block for taps within 256 * wq samples
+// (float64: `side` / `fork` / `join` -- a second stream and two events of the plan -- let the few two-piece edge items of the
+// split bands, a dozen long workgroups, run beside the band items instead of alone on the chip)
 template <typename T>
-int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st);
+int launch_block(const BlockArgs<T>& a, int demod, int64_t n_channels, hipStream_t st, hipStream_t side = nullptr,
+                 hipEvent_t fork = nullptr, hipEvent_t join = nullptr);
 // a0: styx table, a2: Stockwell table; both must agree on which panels (coefficients, bits) are stored
 template <typename T>
 // (n_edge: how many of the list's last items are edge items of the split bands)

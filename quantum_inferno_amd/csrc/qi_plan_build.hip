@@ -552,6 +552,28 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       il.nedge_items = (int32_t)items.size() - il.nitems;
     }
     il.h_items = items;
+    if (F64 && demod && !list.empty()) {
+      // demodulation tables of the float64 Stockwell bands (exact integer phases, long double): per band exp(-2 pi i idx 256 i / n)
+      const long double two_pi = 6.283185307179586476925286766559005768L;
+      auto root = [&](int64_t m) {
+        const long double ang = -two_pi * (long double)(((m % p->n) + p->n) % p->n) / (long double)p->n;
+        return make_double2((double)cosl(ang), (double)sinl(ang));
+      };
+      std::vector<double2> pw(list.size() * 16);
+      for (size_t q = 0; q < list.size(); ++q)
+        for (int i = 0; i < 16; ++i) pw[q * 16 + i] = root((int64_t)(((__int128)list[q].shift * 256 * i) % p->n));
+      QI_HIP(hipMalloc((void**)&il.d_demod_pow, pw.size() * sizeof(double2)));
+      QI_HIP(hipMemcpy(il.d_demod_pow, pw.data(), pw.size() * sizeof(double2), hipMemcpyHostToDevice));
+      if (!p->d_demod_t1 && p->n >= 1024) {
+        std::vector<double2> t1((size_t)(p->n / 1024)), t2(1024);
+        for (int64_t j = 0; j < p->n / 1024; ++j) t1[(size_t)j] = root(1024 * j);
+        for (int64_t j = 0; j < 1024; ++j) t2[(size_t)j] = root(j);
+        QI_HIP(hipMalloc((void**)&p->d_demod_t1, t1.size() * sizeof(double2)));
+        QI_HIP(hipMemcpy(p->d_demod_t1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
+        QI_HIP(hipMalloc((void**)&p->d_demod_t2, t2.size() * sizeof(double2)));
+        QI_HIP(hipMemcpy(p->d_demod_t2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
+      }
+    }
     QI_HIP(hipMalloc((void**)&il.d_bands, list.size() * sizeof(native::BlockBandT<T>)));
     QI_HIP(hipMemcpy(il.d_bands, list.data(), list.size() * sizeof(native::BlockBandT<T>), hipMemcpyHostToDevice));
     QI_HIP(hipMalloc((void**)&il.d_items, items.size() * sizeof(native::BlockItem)));

@@ -1055,6 +1055,10 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       b.items = il.d_items;
       b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);
       b.bank = static_cast<const cplx<T>*>(bt.bank);
+      b.edge_wq = (int32_t)(p->native_split_e / 512);
+      b.demod_pow = static_cast<const cplx<T>*>(il.d_demod_pow);
+      b.demod_t1 = p->d_demod_t1;
+      b.demod_t2 = p->d_demod_t2;
       b.sig = sig + c0 * n;
       b.coef = coef;
       b.bits = bits;
@@ -1070,7 +1074,12 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       b.eps = eps;
       b.two_over_n = (float)(2.0 / (double)n);
       p->prof.begin(st, QI_STAGE_BLOCK);
-      QI_TRY(native::launch_block<T>(b, bt.demod, ct, st));
+      if (b.nedge_items > 0 && !p->side) {
+        QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+      }
+      QI_TRY(native::launch_block<T>(b, bt.demod, ct, st, p->side, p->ev_fork, p->ev_join));
       p->prof.end(QI_STAGE_BLOCK, st);
     }
     p->prof.begin(st, QI_STAGE_EPILOGUE);

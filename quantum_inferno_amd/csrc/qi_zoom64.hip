@@ -206,12 +206,6 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
 // becomes a scalar load (s_load_dword*) -- used for the band descriptors and the wave-uniform carrier factors.  (The
 // WINDOWS were first read this way too: correct, and 20 % slower than k_z64_interp -- the scalar cache is no streaming
 // path: waves waited 60-70 % of their life for s_load data.  They come through a vector register and v_readlane now.)
-template <typename V>
-using z64_cptr = const V __attribute__((address_space(4)))*;
-template <typename V>
-__device__ __forceinline__ z64_cptr<V> as_const(const V* p) {
-  return reinterpret_cast<z64_cptr<V>>(reinterpret_cast<uintptr_t>(p));
-}
 
 #ifdef QI_NATIVE_DEBUG
 #define QI_ZDBG(bit) (a.debug & (bit))
