@@ -329,6 +329,20 @@ struct qi_plan {
   // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
   // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
   int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
+  // qi_cwt_stx as a captured graph (QI_PLAN_GRAPH): one entry per set of caller buffers
+  struct GraphEntry {
+    const void* sig = nullptr;
+    int64_t C = 0;
+    qi_tfr_out oc{}, os{};
+    uint64_t gen = 0;
+    int seen = 0;  // calls with this key so far (the first runs eagerly: lazy set-up -- item lists, function attributes)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  std::vector<GraphEntry> graphs;
+  int native_graph = 0;     // QI_PLAN_GRAPH / QI_NATIVE_GRAPH
+  hipStream_t cap_stream = nullptr;  // the stream a call is captured on (the caller's may be the legacy default stream, which cannot capture)
+  bool capturing = false;   // inside the capture of a qi_cwt_stx call: the fork to the side stream was recorded at its start
   int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
                            // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
                            // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
@@ -344,7 +358,7 @@ struct qi_plan {
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen
                                 // inputs batched: -35 % of that stage at 16 records, -20 % at one); 0: never
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_parts = nullptr;
   // split bands of the styx bank (atoms longer than the record): zoom engine + edge pieces, see split_taper
   int native_split = 1;        // 0: such bands stay on the two-pass kernels
   int64_t native_split_e = 1024;  // taper length in samples (512, 1024 or 2048: the edge pieces' reach group)

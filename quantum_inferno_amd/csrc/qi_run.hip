@@ -459,7 +459,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     const bool joint_blk = finishing && blocks && p->native_fuse > 1 && finish->ct == ct && !finish->demod && bt.demod &&
                            (finish->blk.coef != nullptr) == (out->coef != nullptr) &&
                            (finish->blk.bits != nullptr) == (out->bits != nullptr);
-    const bool pair = joint_blk && p->native_pair && !overlap;
+    const bool pair = joint_blk && (p->native_pair || p->capturing) && !overlap;
     if (pair && !p->side) {
       QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
       QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
@@ -525,10 +525,26 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       p->prof.unchain_span();
       return QI_OK;
     };
-    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
-    if (pair) {
+    // A captured qi_cwt_stx call (QI_PLAN_GRAPH): the joint block launch is a branch of the graph that starts behind the
+    // clearing of BOTH tables' partial sums and nothing else -- the fork is recorded in the first (styx) run behind its
+    // clearing; the second run clears its partials on the side stream in front of the block launch and lets its own stream
+    // wait for just that.
+    const bool cap_pair = pair && p->capturing;
+    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, cap_pair ? p->side : st));
+    if (p->capturing && deferring && c0 == 0) {
       QI_HIP(hipEventRecord(p->ev_fork, st));
       QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    }
+    if (pair) {
+      if (cap_pair) {
+        if (clear_parts) {
+          QI_HIP(hipEventRecord(p->ev_parts, p->side));
+          QI_HIP(hipStreamWaitEvent(st, p->ev_parts, 0));
+        }
+      } else {
+        QI_HIP(hipEventRecord(p->ev_fork, st));
+        QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      }
       QI_TRY(launch_blocks(p->side, 1));
       QI_HIP(hipEventRecord(p->ev_join, p->side));
     }

@@ -992,6 +992,40 @@ def test_staged_result_copy_is_bit_equal(monkeypatch):
         assert all(np.array_equal(r, ref) for r in out[key])
 
 
+def test_cwt_stx_graph_mode_is_bit_equal():
+    """QI_PLAN_GRAPH: qi_cwt_stx calls of one or two float32 records are captured once per set of buffers as a HIP graph (the
+    joint block launch a branch beside the forward / coarse / interpolation chain) and replayed: the same kernels on the
+    same data -- every output bit-equal to the eager launches, for replays, for a second set of buffers and after the records
+    change in place."""
+    n, fs, order = 1 << 18, 1000.0, 3
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    for channels in (1, 2):
+        x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, channels, np.float32) for c in range(channels)])).cuda()
+        plans = []
+        for graph in (False, True):
+            plan = engine.TfrPlan(n, np.float32, None, engine.TfrPlan.workspace_for(n, nb, np.float32, channels), graph=graph)
+            plan.set_styx_bank(order, fs)
+            plan.set_stx_bands(order, fs)
+            plans.append(plan)
+        eager, graph = plans
+        ref = eager.cwt_stx(x, coef=True, reductions=True)
+        out_a = graph.cwt_stx(x, coef=True, reductions=True)       # call 1 with these buffers: eager inside the library
+        out_b = graph.cwt_stx(x, coef=True, reductions=True)       # another set of buffers
+        for k in range(4):                                           # call 2 captures, 3 and 4 replay
+            graph.cwt_stx(x, out=out_a)
+            graph.cwt_stx(x, out=out_b)
+            for got in (out_a, out_b):
+                for g, r in zip(got, ref):
+                    assert torch.equal(g.coef, r.coef) and torch.equal(g.reduced, r.reduced), (channels, k)
+        x.mul_(0.5)  # the records change in place: the replayed graph reads the new data
+        ref = eager.cwt_stx(x, coef=True, reductions=True)
+        graph.cwt_stx(x, out=out_a)
+        for g, r in zip(out_a, ref):
+            assert torch.equal(g.coef, r.coef) and torch.equal(g.reduced, r.reduced)
+        eager.close()
+        graph.close()
+
+
 def test_plan_ring_matches_single_plan():
     """PlanRing: independent records on alternating plans / streams give the results of one plan on one stream, bit for
     bit, and every result carries the event that follows its launches."""
