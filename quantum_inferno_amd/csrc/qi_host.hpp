@@ -353,6 +353,7 @@ struct qi_plan {
   double2* d_demod_t1 = nullptr;  // float64 block engine, Stockwell demodulation: exp(-2 pi i 1024 j / n), j < n / 1024
   double2* d_demod_t2 = nullptr;  // ... exp(-2 pi i j / n), j < 1024
   int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
+  int native_z64_rows = 0;  // rows (band chunks = per-time planes) of the fine launches of a call together, at least
   int native_f64 = 1;      // float64 plans run on the native engines in double arithmetic (2^20 / 2^21-point transforms)
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen

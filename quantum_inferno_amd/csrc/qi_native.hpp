@@ -321,10 +321,13 @@ void z64_weights(int log2d, double* w /*[1 << log2d][kZ64Taps]*/);
 // its grid, the shorter the interpolator that reaches the same error (worst case of a unit tone anywhere in the band, double
 // weights: 16 taps at >= 4 x oversampling 2.8e-12, 12 at >= 8 x 3.9e-13, 10 at >= 16 x 4.1e-14, 8 at >= 32 x 7.2e-14, 6 at
 // >= 64 x 2.1e-12) -- on the coarsest grid, where every narrower band lands, most bands of an order-12 table take 6 - 10 taps.
-constexpr int kZ64FineClasses = 7;  // 0..2: grids of Lf / 64, Lf / 32, Lf / 16 samples, 16 taps; 3..6: coarsest grid, 12 / 10 / 8 / 6 taps
-constexpr int kZ64FineLevels = 3;   // coarse grids the fine kernel takes (the finer two stay with k_z64_interp)
+// (measured per grid against k_z64_interp, 4 records, order 12: Lf / 64 -8 %, Lf / 32 -5 %, Lf / 16 +15 % -- a wave-step that
+// spans four coarse intervals pays 46 v_readlane per output -- so the fine kernel takes the two coarsest grids)
+constexpr int kZ64FineLevels = 2;   // coarse grids the fine kernel takes (the finer three stay with k_z64_interp)
+constexpr int kZ64FineClasses = kZ64FineLevels + 4;  // [0, kZ64FineLevels): grids of Lf / 64, Lf / 32 samples, 16 taps; then the
+                                                     // coarsest grid with 12 / 10 / 8 / 6 taps
 constexpr int z64f_level(int c) { return c < kZ64FineLevels ? c : 0; }
-constexpr int z64f_ntap(int c) { return c < kZ64FineLevels ? 16 : (c == 3 ? 12 : (c == 4 ? 10 : (c == 5 ? 8 : 6))); }
+constexpr int z64f_ntap(int c) { return c < kZ64FineLevels ? 16 : 12 - 2 * (c - kZ64FineLevels); }
 constexpr int z64f_oversampling(int c) { return c < kZ64FineLevels ? 4 : (8 << (c - kZ64FineLevels)); }
 constexpr int z64f_span(int c) { return 1 << z64f_level(c); }                  // S
 constexpr int z64f_win(int c) { return z64f_ntap(c) + z64f_span(c) - 1; }      // weights per lane

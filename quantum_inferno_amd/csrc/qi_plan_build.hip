@@ -13,11 +13,11 @@ bool native_len_ok(int64_t Lf) { return Lf == (1ll << 20) || Lf == (1ll << 21); 
 bool native_wanted(const qi_plan* p, int kind) {
   if (p->d.engine == QI_ENGINE_HIPFFT) return false;
   const int64_t Lf = kind == 0 ? p->L : p->n;
-  // float64: the exact two-pass kernels only (their transform lengths); no zoom / block / split approximations
-  if (p->d.dtype == QI_F64) return p->native_f64 && is_pow2(p->n) && native_len_ok(Lf);
+  if (p->d.dtype == QI_F64 && !p->native_f64) return false;
   if (is_pow2(p->n) && native_len_ok(Lf)) return true;
   // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
-  // band), and those engines take any power-of-two length from 2^15: the table build decides
+  // band), and those engines -- in float32 and, since round 4, their float64 twins (float64 zoom, k_block64, split bands) --
+  // take any power-of-two length from 2^15: the table build decides
   return kind != 1 && is_pow2(p->n) && p->n >= (1 << 15) && Lf <= (1ll << 26);
 }
 
@@ -151,7 +151,9 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       }
       lvl[0].clear();
       int32_t pos = 0;
-      for (int c : {0, 3, 4, 5, 6}) {
+      std::vector<int> order0{0};  // list order of the coarsest grid: the 16-tap class, then the shorter interpolators
+      for (int c = native::kZ64FineLevels; c < native::kZ64FineClasses; ++c) order0.push_back(c);
+      for (int c : order0) {
         t.zf_first[c] = pos;
         t.zf_count[c] = (int32_t)cls[c].size();
         pos += t.zf_count[c];
@@ -213,10 +215,13 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
       QI_HIP(hipMalloc((void**)&t.d_z64_wave_ph, wave.size() * sizeof(double2)));
       QI_HIP(hipMemcpy(t.d_z64_wave_ph, wave.data(), wave.size() * sizeof(double2), hipMemcpyHostToDevice));
     }
-    if (tune_env("QI_NATIVE_VERBOSE"))
-      fprintf(stderr, "[qi plan] table %d: float64 zoom bands per level %d %d %d %d %d (fine classes %d %d %d | %d %d %d %d), two-pass bands %zu\n",
-              kind, t.z64_count[0], t.z64_count[1], t.z64_count[2], t.z64_count[3], t.z64_count[4], t.zf_count[0], t.zf_count[1],
-              t.zf_count[2], t.zf_count[3], t.zf_count[4], t.zf_count[5], t.zf_count[6], rest.size());
+    if (tune_env("QI_NATIVE_VERBOSE")) {
+      fprintf(stderr, "[qi plan] table %d: float64 zoom bands per level %d %d %d %d %d, two-pass bands %zu; fine classes (taps: bands)", kind,
+              t.z64_count[0], t.z64_count[1], t.z64_count[2], t.z64_count[3], t.z64_count[4], rest.size());
+      for (int c = 0; c < native::kZ64FineClasses; ++c)
+        fprintf(stderr, " %d@L%d: %d", native::z64f_ntap(c), native::z64f_level(c), t.zf_count[c]);
+      fprintf(stderr, "\n");
+    }
     bands.swap(rest);
   }
   t.h_rows.clear();
@@ -737,7 +742,10 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     // (a band of the widest reach groups -- half of each 4096-sample block is overlap there -- goes to the zoom
     // engine instead when its spectrum fits one of its grids)
     // (float64: a band the float64 zoom takes -- support within Lf / 16 bins -- stays there)
-    const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L);
+    // (... its finest grid, Lf / 4 samples, oversamples it four times: at transform lengths below 2^19 the one-pass loader's
+    // limit is wider than that, and such a band belongs to the block engine)
+    const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L) &&
+                           4 * len <= ((L / 64) << (p->native_z64_levels - 1));
     if (can_block && block_group_of(w) > 0 && !z64_first &&
         !(block_group_of(w) > p->native_blk_maxwq && zoom_class(p, bank, L, len) >= 0)) {
       BlockPick pk{j, block_group_of(w), 0};
@@ -931,7 +939,7 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
                               zoom_class(p, 2, p->n, (int64_t)(2 * kh0 + 1)) >= 0;
       const double kh64 = std::floor(cut / coef[j]);
       const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, 2) && 2 * kh64 + 1 <= (double)narrow_limit(p, 2, p->n) &&
-                             2 * kh64 + 1 < (double)p->n;
+                             2 * kh64 + 1 < (double)p->n && 4.0 * (2 * kh64 + 1) <= (double)((p->n / 64) << (p->native_z64_levels - 1));
       if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 && !zoom_first && !z64_first) {
         BlockPick pk{j, block_group_of(reach), shift_index[j]};
         // the band's filter spectrum is the Gaussian window itself, centred on the band's shift index
@@ -961,8 +969,19 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
     }
     bool two_pass_free = true;  // no band for pass 1 / pass 2 (their transform lengths are 2^20 and 2^21 only)
     for (const auto& d : bands) two_pass_free = two_pass_free && d.mode >= 2;
-    if (native_len_ok(p->n) || two_pass_free) {
+    // (float64: the float64 zoom takes its bands inside upload_native_table -- what it leaves is known afterwards)
+    const bool f64_maybe = p->d.dtype == QI_F64 && z64_table(p, 2);
+    if (native_len_ok(p->n) || two_pass_free || f64_maybe) {
       int rc = upload_native_table(p, 2, p->n, bands);
+      if (rc == QI_OK && !native_len_ok(p->n) && !p->nat[2].h_rows.empty()) {
+        p->nat[2].release();  // bands are left for the two-pass kernels at a length they do not run: the hipFFT engine takes the table
+        p->blk[2].release();
+        if (p->d.engine == QI_ENGINE_NATIVE) {
+          set_error("native engine: this Stockwell band table needs the two-pass kernels, which run 2^20 / 2^21 samples only");
+          return QI_ERR_UNSUPPORTED;
+        }
+        return QI_OK;
+      }
       if (rc == QI_OK) {
         p->nat[2].nbands = B;
         rc = p->d.dtype == QI_F64 ? build_block_stx<double>(p, picks, coef, nullptr) : build_block_stx<float>(p, picks, coef, nullptr);

@@ -865,7 +865,9 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     // epilogue), at least one row
     double work = 0.0, mine = (double)t.zf_count[c] * (2.0 * native::z64f_win(c) + 40.0);
     for (int q = 0; q < native::kZ64FineClasses; ++q) work += (double)t.zf_count[q] * (2.0 * native::z64f_win(q) + 40.0);
-    int nr = (int)std::ceil((double)p->native_wgs * (mine / work) / (double)(tiles_f * C));
+    // (native_z64_rows: rows of all classes together a call should have at least)
+    const double want_rows = std::max<double>((double)p->native_z64_rows, (double)p->native_wgs / (double)(tiles_f * C));
+    int nr = (int)std::ceil(want_rows * (mine / work));
     frow[c] = nr < 1 ? 1 : (nr > t.zf_count[c] ? t.zf_count[c] : nr);
     chunk_total += frow[c];
   }
@@ -1030,7 +1032,8 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
     }
     p->prof.begin(st, QI_STAGE_ZOOM);
-    for (int c : {6, 5, 4, 3, 0, 1, 2}) {
+    for (int ci = 0; ci < native::kZ64FineClasses; ++ci) {
+      const int c = native::kZ64FineClasses - 1 - ci;  // (the shortest interpolators -- the classes with the most bands -- first)
       if (t.zf_count[c] == 0) continue;
       const int g = native::z64f_level(c);
       native::Z64FineArgs f{};

@@ -398,16 +398,11 @@ __global__ void __launch_bounds__(64) k_z64_pad(cd* __restrict__ Z, int64_t M) {
   else if (i < 2 * kZ64Pad) z[M + i] = z[i];             // back pad <- first samples (i - kZ64Pad + kZ64Pad)
 }
 
-template <int KIND, bool COEF>
+template <int KIND, bool COEF, int CLS = 0>
 void launch_fine_cls(const Z64FineArgs& a, dim3 grid, hipStream_t st) {
-  switch (a.cls) {
-    case 0: k_z64_fine<KIND, 0, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    case 1: k_z64_fine<KIND, 1, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    case 2: k_z64_fine<KIND, 2, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    case 3: k_z64_fine<KIND, 3, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    case 4: k_z64_fine<KIND, 4, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    case 5: k_z64_fine<KIND, 5, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
-    default: k_z64_fine<KIND, 6, COEF><<<grid, kZ64Threads, 0, st>>>(a); break;
+  if constexpr (CLS < kZ64FineClasses) {
+    if (a.cls == CLS) k_z64_fine<KIND, CLS, COEF><<<grid, kZ64Threads, 0, st>>>(a);
+    else launch_fine_cls<KIND, COEF, CLS + 1>(a, grid, st);
   }
 }
 

@@ -719,14 +719,16 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
     plan.close()
 
 
-@pytest.mark.parametrize("log2n,name", [(19, "cwt"), (21, "stx")])
-def test_float64_native_engine_other_lengths(log2n, name):
-    """The float64 engines run transforms of 2^20 / 2^21 points: the zero-padded styx CWT of a 2^19-sample record and the
-    Stockwell transform of a 2^21-sample record are the other two shapes they take (other tile sizes and coarse grids of the
-    float64 zoom).  Against the hipFFT engine: every row to its own maximum, and the fused reductions."""
+@pytest.mark.parametrize("log2n,name,order", [(19, "cwt", 6), (21, "stx", 6), (16, "cwt", 12), (16, "stx", 3), (18, "cwt", 3),
+                                              (18, "stx", 12), (22, "cwt", 6), (22, "stx", 6), (15, "cwt", 6)])
+def test_float64_native_engine_other_lengths(log2n, name, order):
+    """The float64 engines (float64 zoom, block engine in double, split bands) at other record lengths than 2^20: every
+    power of two from 2^15 to 2^22 whose band table leaves nothing for the two-pass kernels (round 3 ran these on the hipFFT
+    engine, 13-25 x slower, except the two shapes with 2^20 / 2^21-point transforms).  Against the ORACLE on bands of every
+    engine at the float64 tolerance, and against the hipFFT engine: every row to its own maximum, and the fused reductions."""
     from quantum_inferno_amd import _lib
 
-    n, fs, order = 1 << log2n, 1000.0, 6
+    n, fs = 1 << log2n, 1000.0
     x = torch.from_numpy(orc.synth_chirp(n, fs, dtype=np.float64)).cuda().unsqueeze(0)
     nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
     ws = engine.TfrPlan.workspace_for(n, nb, np.float64, 1)
@@ -736,9 +738,16 @@ def test_float64_native_engine_other_lengths(log2n, name):
         (plan.set_styx_bank if name == "cwt" else plan.set_stx_bands)(order, fs)
     which = 0 if name == "cwt" else 2
     assert nat.stage_bands("zoom")[which] + nat.stage_bands("pass2")[which] + nat.stage_bands("block")[which] == nb
-    assert nat.stage_bands("zoom")[which] > 0 and nat.stage_bands("block")[which] > 0
+    assert nat.stage_bands("zoom")[which] > 0 and nat.stage_bands("block")[which] > 0  # (zero would mean: the hipFFT engine ran it)
     a = getattr(nat, name)(x, coef=True, reductions=True)
     b = getattr(ref, name)(x, coef=True, reductions=True)
+    pick = sorted({0, 1, nb // 4, nb // 2, (3 * nb) // 4, nb - 2, nb - 1})
+    _, _, want = (orc.cwt_fft if name == "cwt" else orc.stx_fft)(order, x[0].cpu().numpy(), fs, bands=pick)
+    got = a.coef[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= TOL[np.float64]["coef"] * float(b.coef.abs().max()), (log2n, name)
+    for i, j in enumerate(pick):
+        assert np.max(np.abs(got[i] - want[i])) <= 5e-9 * np.max(np.abs(want[i])), (log2n, name, j)
+    assert np.allclose(a.power_band[0][torch.tensor(pick, device="cuda")].cpu().numpy(), (np.abs(want) ** 2).sum(axis=1), rtol=1e-10)
     peak = b.coef[0].abs().amax(dim=1)
     err = (a.coef[0] - b.coef[0]).abs().amax(dim=1) / peak
     assert float(err.max()) <= 5e-9, (int(err.argmax()), float(err.max()))
