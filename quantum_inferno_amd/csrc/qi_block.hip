@@ -1419,6 +1419,138 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<doubl
   }
 }
 
+// ---- float64 zoom, coarse stage in LDS (round 4) ---------------------------------------------------------------------
+// The coarse samples of a band -- b[tau] = sum_q Yb[q] exp(2 pi i q tau / M), M = 4096 P, Yb the band's occupied bins at
+// baseband -- for one residue tau1 = tau mod P are ONE 4096-point transform of the bins folded modulo 4096 and twiddled
+// (zoom_gather16 of the float32 engine, here in double): a workgroup forms the 4096 inputs of its plane in registers from
+// the record's spectrum and the compact bank (or the Stockwell window), transforms them in LDS and stores the samples
+// tau = P tau2 + tau1 into the band's coarse array [kZ64Pad | M | kZ64Pad] (natural order: what k_z64_fine reads), pads
+// included.  Against gather launch + batched hipFFT (3-5 passes over zero-filled M-point arrays) + pad launch this moves
+// the coarse array through HBM once.  The fold costs ~ len / 4096 terms per input: it pays on the three coarsest grids
+// (P <= 32 at Lf = 2^21); the two finest (len up to 131 072 bins: 33 terms, more arithmetic than a full transform) stay
+// with hipFFT.
+template <bool STX>
+__device__ __forceinline__ void z64_gather16(const Z64Args& a, const BandDesc& bd, const uint32_t tau1, const int col,
+                                             const double2* __restrict__ X, double2 (&v)[16]) {
+  const int32_t M = (int32_t)a.M, P = M / kBlk;
+  const int32_t kc = STX ? 0 : bd.k_lo + bd.k_len / 2;
+  const int32_t ks_lo = bd.k_lo - kc, ks_hi = ks_lo + bd.k_len;  // support in baseband bins
+  const uint32_t lmask = (uint32_t)a.Lf - 1u;
+  const int nterm = (bd.k_len + kBlk - 1) / kBlk;
+  int32_t ks0[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    v[b] = make_double2(0.0, 0.0);
+    ks0[b] = ks_lo + (((col + 256 * b) - ks_lo) & (kBlk - 1));
+  }
+  // block twiddles exp(2 pi i r tau1 / P): r = r_a for the elements whose first bin lies in the block of ks_lo, r_a + 1 for
+  // the others, advanced by one block per term
+  const uint32_t r_a = ((uint32_t)ks_lo & ((uint32_t)M - 1u)) / kBlk;
+  const uint32_t edge = (((uint32_t)ks_lo & ((uint32_t)M - 1u)) | (uint32_t)(kBlk - 1)) + 1u;
+  double sf, cf;
+  sincospi(2.0 * (double)((r_a * tau1) & (uint32_t)(P - 1)) / (double)P, &sf, &cf);
+  double2 w_a = make_double2(cf, sf);
+  sincospi(2.0 * (double)(tau1 & (uint32_t)(P - 1)) / (double)P, &sf, &cf);
+  const double2 w_step = make_double2(cf, sf);
+  double2 w_b = cmul(w_a, w_step);
+  const uint32_t base_mod = (uint32_t)ks_lo & ((uint32_t)M - 1u);
+  for (int m = 0; m < nterm; ++m) {
+#pragma unroll
+    for (int hb = 0; hb < 16; hb += 8) {  // eight elements' loads in flight at a time
+      double2 x[8], h[8];
+      bool on[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int32_t ks = ks0[hb + q] + kBlk * m;
+        on[q] = ks < ks_hi;
+        const int32_t k = kc + ks;
+        x[q] = make_double2(0.0, 0.0);
+        h[q] = x[q];
+        if (on[q]) {
+          if (STX) {
+            x[q] = X[(uint32_t)(k + (int32_t)bd.shift) & lmask];
+          } else {
+            x[q] = X[(uint32_t)k & lmask];
+            h[q] = a.Hc[bd.src_off + (k - bd.k_lo)];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int b = hb + q;
+        if (!on[q]) continue;
+        double2 y;
+        if (STX) {
+          const double g0 = bd.coef * (double)(kc + ks0[b] + kBlk * m);
+          const double g = exp2_t(-g0 * g0) * a.inv_len;
+          y = make_double2(x[q].x * g, x[q].y * g);
+        } else {
+          y = cmul(x[q], h[q]);
+        }
+        const bool second = base_mod + (uint32_t)(ks0[b] - ks_lo) >= edge;
+        const double2 t = cmul(y, second ? w_b : w_a);
+        v[b].x += t.x;
+        v[b].y += t.y;
+      }
+    }
+    w_a = w_b;
+    w_b = cmul(w_b, w_step);
+  }
+  // outer twiddle exp(2 pi i (col + 256 b) tau1 / M) = e0 s^b (exact integer phases), powers by binary products
+  sincospi(2.0 * (double)(((uint32_t)col * tau1) & ((uint32_t)M - 1u)) / (double)M, &sf, &cf);
+  const double2 e0 = make_double2(cf, sf);
+  sincospi(2.0 * (double)((256u * tau1) & ((uint32_t)M - 1u)) / (double)M, &sf, &cf);
+  const double2 s1 = make_double2(cf, sf), s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4);
+  double2 pw = e0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {  // (Gray-code-free walk: pw(b) from pw(b - lowbit(b)) needs sixteen live values; b -> b + 1 by s1,
+    v[b] = cmul(v[b], pw);        //  fifteen roundings deep, is far inside the float64 tolerance and holds one)
+    pw = cmul(pw, s1);
+  }
+  (void)s2; (void)s4; (void)s8;
+}
+
+template <bool STX>
+__global__ void __launch_bounds__(kBlkThreads, 2) k_z64_coarse(Z64Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem64[];
+  double2* buf = reinterpret_cast<double2*>(smem64);
+  double2* tw256 = buf + kBlkBuf;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
+  const int32_t P = (int32_t)(a.M / kBlk);
+  // Consecutive workgroups go to consecutive XCDs; the P planes of a band fill the same 128-byte lines of its coarse array
+  // (sample tau = P tau2 + tau1, 16 bytes each) and gather the same bins: consecutive planes sit behind ONE L2 -- workgroup
+  // w takes plane (w mod 8) (planes / 8) + w / 8 of the launch (planes = bands x P is a multiple of 8)
+  const uint32_t planes = (uint32_t)a.nbands * (uint32_t)P;
+  const uint32_t pi = (blockIdx.x & 7u) * (planes >> 3) + (blockIdx.x >> 3);
+  const uint32_t band = pi / (uint32_t)P, tau1 = pi - band * (uint32_t)P;
+  const BandDesc bd = a.bands[band];
+  const int64_t ch = blockIdx.y;
+  double2 v[16];
+  z64_gather16<STX>(a, bd, tau1, col, a.X + ch * a.Lf, v);
+  {
+    double s, c;
+    sincospi((double)tid * (2.0 / 256.0), &s, &c);
+    tw256[tid] = make_double2(c, s);
+  }
+  double2 w;
+  {
+    double s, c;
+    sincospi((double)col * (2.0 / 4096.0), &s, &c);
+    w = make_double2(c, s);
+  }
+  fft4096<double, 1>(v, buf, tw256, w, tid, col);
+  double2* __restrict__ z = a.Z + ((int64_t)ch * a.nbands + band) * (a.M + 2 * kZ64Pad) + kZ64Pad;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int64_t tau = (int64_t)P * (col + 256 * c) + tau1;
+    const double2 val = v[brev(c, 4)];
+    z[tau] = val;
+    if (tau < kZ64Pad) z[a.M + tau] = val;            // back pad <- first samples
+    if (tau >= a.M - kZ64Pad) z[tau - a.M] = val;     // front pad <- last samples
+  }
+}
+
 // long-block items (BlockItem::wq = kBlkLongWq) have kernels of their own: their register budget (the even samples of a
 // band are held while its odd samples are transformed) would spill inside k_block / k_block_dual
 template <typename T, bool DEMOD, bool COEF, bool BITS>
@@ -1871,6 +2003,25 @@ int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channe
   if (beside) QI_HIP(hipStreamWaitEvent(st, join, 0));
 #undef QI_E64_ALL
 #undef QI_E64
+  return QI_OK;
+}
+
+int launch_z64_coarse(const Z64Args& a, int64_t n_channels, hipStream_t st) {
+  if (a.nbands <= 0) return QI_OK;
+  const int64_t P = a.M / kBlk;
+  if (P < 8 || P * kBlk != a.M || (a.M & (a.M - 1)) != 0) {
+    set_error("float64 zoom: a coarse grid of %lld samples has no in-LDS coarse stage", (long long)a.M);
+    return QI_ERR_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)(a.nbands * P), (unsigned)n_channels, 1);
+  if (a.kind == 2) {
+    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_z64_coarse<true>), kBlk64Lds));
+    k_z64_coarse<true><<<grid, kBlkThreads, kBlk64Lds, st>>>(a);
+  } else {
+    QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_z64_coarse<false>), kBlk64Lds));
+    k_z64_coarse<false><<<grid, kBlkThreads, kBlk64Lds, st>>>(a);
+  }
+  QI_LAUNCH_CHECK();
   return QI_OK;
 }
 

@@ -353,6 +353,8 @@ struct qi_plan {
   double2* d_demod_t1 = nullptr;  // float64 block engine, Stockwell demodulation: exp(-2 pi i 1024 j / n), j < n / 1024
   double2* d_demod_t2 = nullptr;  // ... exp(-2 pi i j / n), j < 1024
   int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
+  int native_z64_block_from = 4;  // a band that needs coarse-grid level >= this (0-based) goes to the block engine when its atom is short enough
+  int native_z64_coarse = 3;  // coarse-grid levels whose coarse stage is one launch of in-LDS plane transforms (the finer ones: hipFFT)
   int native_z64_rows = 0;  // rows (band chunks = per-time planes) of the fine launches of a call together, at least
   int native_f64 = 1;      // float64 plans run on the native engines in double arithmetic (2^20 / 2^21-point transforms)
   int native_gather_fused = 1;  // zoom engine: from this many records per tile the coarse stage forms its inputs in registers

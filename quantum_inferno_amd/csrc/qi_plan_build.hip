@@ -326,7 +326,10 @@ int fill_native_bank(qi_plan* p, qi_plan::NativeTable& t, int circular, int64_t 
       if (d.mode != 1) {
         // zoom bands of the linear (styx) table: panel sample t is full-length sample t + n/2 - 1; the odd sample is a
         // phase ramp on the band's baseband bins, exp(-2 pi i (k - k_c) / L), folded into the compact bank here
-        const double ramp = (d.mode >= 2 && !circular) ? -1.0 / (double)L : 0.0;
+        // (float64: the same for the bands the float64 zoom takes -- upload_native_table's rule)
+        const bool z64_band = p->d.dtype == QI_F64 && z64_table(p, 0) && d.mode == 0 &&
+                              4 * (int64_t)d.k_len <= ((L / 64) << (p->native_z64_levels - 1));
+        const double ramp = ((d.mode >= 2 || z64_band) && !circular) ? -1.0 / (double)L : 0.0;
         QI_TRY(native::launch_copy_window<T>(rows + (int64_t)jj * L, static_cast<cplx<T>*>(t.Hc) + d.src_off, d.k_lo,
                                               d.k_len, circular, 1.0 / (double)L, L, st, ramp, d.k_len / 2));
       }
@@ -744,8 +747,12 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
     // (float64: a band the float64 zoom takes -- support within Lf / 16 bins -- stays there)
     // (... its finest grid, Lf / 4 samples, oversamples it four times: at transform lengths below 2^19 the one-pass loader's
     // limit is wider than that, and such a band belongs to the block engine)
-    const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L) &&
-                           4 * len <= ((L / 64) << (p->native_z64_levels - 1));
+    // (... and not on one of its finest grids when the block engine can take the band: a band of 65 536 - 131 072 bins costs
+    // the float64 zoom 13.5 us per record -- a 2^19-point coarse transform and the LDS-window interpolation kernel --
+    // against 7.4 us on the block engine, measured at order 12 x 4 records: native_z64_block_from)
+    bool z64_first = p->d.dtype == QI_F64 && z64_table(p, bank) && len > 0 && len <= narrow_limit(p, bank, L) &&
+                     4 * len <= ((L / 64) << (p->native_z64_levels - 1));
+    if (z64_first && can_block && block_group_of(w) > 0 && 4 * len > ((L / 64) << (p->native_z64_block_from - 1))) z64_first = false;
     if (can_block && block_group_of(w) > 0 && !z64_first &&
         !(block_group_of(w) > p->native_blk_maxwq && zoom_class(p, bank, L, len) >= 0)) {
       BlockPick pk{j, block_group_of(w), 0};
@@ -938,8 +945,12 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
       const bool zoom_first = block_group_of(reach) > p->native_blk_maxwq && 2 * kh0 + 1 < (double)p->n &&
                               zoom_class(p, 2, p->n, (int64_t)(2 * kh0 + 1)) >= 0;
       const double kh64 = std::floor(cut / coef[j]);
-      const bool z64_first = p->d.dtype == QI_F64 && z64_table(p, 2) && 2 * kh64 + 1 <= (double)narrow_limit(p, 2, p->n) &&
-                             2 * kh64 + 1 < (double)p->n && 4.0 * (2 * kh64 + 1) <= (double)((p->n / 64) << (p->native_z64_levels - 1));
+      bool z64_first = p->d.dtype == QI_F64 && z64_table(p, 2) && 2 * kh64 + 1 <= (double)narrow_limit(p, 2, p->n) &&
+                       2 * kh64 + 1 < (double)p->n && 4.0 * (2 * kh64 + 1) <= (double)((p->n / 64) << (p->native_z64_levels - 1));
+      // (a band of the float64 zoom's finest grids goes to the block engine when that can take it: native_z64_block_from)
+      if (z64_first && can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 &&
+          4.0 * (2 * kh64 + 1) > (double)((p->n / 64) << (p->native_z64_block_from - 1)))
+        z64_first = false;
       if (can_block && sigma[j] >= 2.75 && block_group_of(reach) > 0 && !zoom_first && !z64_first) {
         BlockPick pk{j, block_group_of(reach), shift_index[j]};
         // the band's filter spectrum is the Gaussian window itself, centred on the band's shift index

@@ -1026,9 +1026,13 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.power_scale = power_scale;
       z.eps = eps;
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-      QI_TRY(native::launch_z64_gather(z, ct, st));
-      QI_TRY(fft_z2z_rows(p->fft, z.Z + native::kZ64Pad, z.M, z.M + 2 * native::kZ64Pad, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
-      QI_TRY(native::launch_z64_pad(z.Z, z.M, (int64_t)z.nbands * ct, st));
+      if (g < p->native_z64_coarse && z.M >= 8 * native::kBlk) {  // the coarsest grids: gather, transform and pads in one launch
+        QI_TRY(native::launch_z64_coarse(z, ct, st));
+      } else {
+        QI_TRY(native::launch_z64_gather(z, ct, st));
+        QI_TRY(fft_z2z_rows(p->fft, z.Z + native::kZ64Pad, z.M, z.M + 2 * native::kZ64Pad, (int64_t)z.nbands * ct, HIPFFT_BACKWARD, st));
+        QI_TRY(native::launch_z64_pad(z.Z, z.M, (int64_t)z.nbands * ct, st));
+      }
       p->prof.end(QI_STAGE_ZOOM_COARSE, st);
     }
     p->prof.begin(st, QI_STAGE_ZOOM);

@@ -44,15 +44,11 @@ __global__ void __launch_bounds__(256) k_z64_gather(Z64Args a) {
       const double w = exp2_t(-e * e) * a.inv_len;
       y = mk<double>(x.x * w, x.y * w);
     } else {
+      // (zero-padded kind: panel sample t is full-length sample t + n / 2 - 1.  The odd sample is taken out of the envelope
+      // -- env'(tau) = env(tau - 1): a phase ramp exp(-2 pi i (i - len / 2) / Lf) on the band's baseband bins, folded into
+      // its compact bank row at plan time (fill_native_bank) -- so that the fine stage reads an aligned window
+      // (tau = t + n / 2); the carrier keeps its phase at tau - 1)
       y = cmul(X[(uint32_t)k & mask], a.Hc[bd.src_off + i]);
-      if (a.kind == 0) {
-        // zero-padded kind: panel sample t is full-length sample t + n / 2 - 1.  The odd sample is taken out of the envelope
-        // here -- env'(tau) = env(tau - 1): a phase ramp exp(-2 pi i (i - len / 2) / Lf) on its baseband bins -- so that the
-        // fine stage reads an aligned window (tau = t + n / 2); the carrier keeps its phase at tau - 1
-        double c, s;
-        unit_root_t<double>((uint32_t)(bd.k_len / 2 - (int32_t)i) & mask, a.two_over_len, &c, &s);
-        y = cmul(y, mk<double>(c, s));
-      }
     }
   }
   a.Z[((int64_t)ch * a.nbands + blockIdx.y) * (a.M + 2 * kZ64Pad) + kZ64Pad + q] = y;
