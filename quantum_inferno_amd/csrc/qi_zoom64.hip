@@ -324,6 +324,9 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
           zr[s] = z.x;
           zi[s] = z.y;
         }
+        // (with the panel stored the store follows its output instead of eight stores back to back at the end of a group:
+        // measured neutral to 1 % faster at order 12 x 4 records)
+        if (COEF && !QI_ZDBG(1)) stream_store(coef_row + tt0 + (uint32_t)(kWave * (g * GS + s)), z);
         const double p = mul_rn(pscale, norm2(z.x, z.y));
         if (!QI_ZDBG(8)) col0[(g * GS + s) * kWave] += p;
         rowacc += p;
@@ -336,7 +339,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
         }
       }
       // (the stores of a group behind ONE wave-uniform branch each, not one per output)
-      if ((COEF || part) && !QI_ZDBG(1)) {
+      if (!COEF && part && !QI_ZDBG(1)) {
 #pragma unroll
         for (int s = 0; s < GS; ++s) stream_store(coef_row + tt0 + (uint32_t)(kWave * (g * GS + s)), mk<double>(zr[s], zi[s]));
       }
