@@ -102,6 +102,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_Z64_ROWS")) p->native_z64_rows = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_COARSE")) p->native_z64_coarse = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_BLOCK_FROM")) p->native_z64_block_from = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK64_WTAB")) p->native_blk64_wtab = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_LEVELS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= native::kZ64Levels) p->native_z64_levels = v;

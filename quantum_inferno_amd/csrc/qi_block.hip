@@ -349,6 +349,16 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
       sparse_head16<T>(v, mk<T>(x.x * r, x.y * r), om);
       if (!QI_BDBG(4)) fft4096_tail<T, 1>(v, buf, tw256, tid, col);
+    } else if (!EDGE && F64 && a.gauss_w) {
+      // float64: the band's 4096 real Gaussian weights from a table made at plan time (32 KB per band, L2-resident: every
+      // block and record multiplies by the same weights) -- in double an exponential is ~22 instructions, sixteen of them
+      // per band and thread were a fifth of the kernel's arithmetic (float32 evaluates them in registers: v_exp_f32)
+      const T* __restrict__ gw = a.gauss_w + (int64_t)(band_first + jj) * kBlk + col;
+      T r[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) r[b] = gw[256 * b];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) v[b] = mk<T>(S[b].x * r[b], S[b].y * r[b]);
     } else if (!EDGE && (F64 || bd.analytic)) {
       // Gaussian filter spectrum in registers: no table traffic (the table rows cost as much L2 bandwidth as the
       // panel costs HBM bandwidth)

@@ -286,6 +286,7 @@ struct qi_plan {
     struct ItemList {
       void* d_bands = nullptr;  // native::BlockBandT<T>[]: all reach groups, group by group (cut 1 keeps some bands on long blocks)
       void* d_demod_pow = nullptr;  // float64 Stockwell tables: [bands][16] demodulation factors (BlockArgs::demod_pow)
+      void* d_gauss_w = nullptr;    // float64 tables: [bands][kBlk] real Gaussian filter weights (BlockArgs::gauss_w)
       std::vector<std::pair<int32_t, int32_t>> h_bands;  // (panel row, blocks) of the block bands
       native::BlockItem* d_items = nullptr;
       int32_t nitems = 0, nplanes = 0;
@@ -300,6 +301,7 @@ struct qi_plan {
       for (auto& v : var) {
         if (v.d_bands) (void)hipFree(v.d_bands);
         if (v.d_demod_pow) (void)hipFree(v.d_demod_pow);
+        if (v.d_gauss_w) (void)hipFree(v.d_gauss_w);
         if (v.d_items) (void)hipFree(v.d_items);
       }
       *this = BlockTable();
@@ -353,6 +355,7 @@ struct qi_plan {
   double2* d_demod_t1 = nullptr;  // float64 block engine, Stockwell demodulation: exp(-2 pi i 1024 j / n), j < n / 1024
   double2* d_demod_t2 = nullptr;  // ... exp(-2 pi i j / n), j < 1024
   int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
+  int native_blk64_wtab = 1;  // float64 block engine: Gaussian filter weights from a plan-time table instead of sixteen exp2 per band and thread
   int native_z64_block_from = 4;  // a band that needs coarse-grid level >= this (0-based) goes to the block engine when its atom is short enough
   int native_z64_coarse = 3;  // coarse-grid levels whose coarse stage is one launch of in-LDS plane transforms (the finer ones: hipFFT)
   int native_z64_rows = 0;  // rows (band chunks = per-time planes) of the fine launches of a call together, at least

@@ -163,6 +163,7 @@ struct BlockArgs {
   const float* lz_w;       // local zoom: [2][8][kBlkLzTaps] interpolation weights for D = 4 and D = 8 (lz_weights)
   // float64 Stockwell tables: demodulation factors from tables (see block_bands): per band of `bands` the sixteen
   // exp(-2 pi i idx 256 i / n), and exp(-2 pi i m / n) = demod_t1[m >> 10] demod_t2[m & 1023]
+  const T* gauss_w;          // float64 tables: [bands][kBlk] the bands' real Gaussian filter weights (null: evaluated in registers)
   const cplx<T>* demod_pow;  // [bands][16]
   const cplx<T>* demod_t1;   // [n / 1024] exp(-2 pi i 1024 j / n)
   const cplx<T>* demod_t2;   // [1024] exp(-2 pi i j / n)

@@ -560,6 +560,26 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       il.nedge_items = (int32_t)items.size() - il.nitems;
     }
     il.h_items = items;
+    if (F64 && p->native_blk64_wtab && !list.empty()) {
+      // float64: the bands' real Gaussian filter weights, weight(k) = amp exp2(-(cw dk)^2) with dk = k - kappa wrapped to
+      // +-kBlk / 2 (Gabor banks: the aliases of the half-sample grid alternate in sign) -- block_bands' formula, in double
+      std::vector<double> gw(list.size() * (size_t)native::kBlk);
+      for (size_t q = 0; q < list.size(); ++q) {
+        const auto& b = list[q];
+        for (int k = 0; k < native::kBlk; ++k) {
+          double dk = (double)(k - b.kappa_int) - (double)b.kappa_frac, amp = (double)b.amp;
+          if (dk > (double)(native::kBlk / 2)) {
+            dk -= (double)native::kBlk;
+            if (!demod) amp = -amp;
+          }
+          if (demod && dk < -(double)(native::kBlk / 2)) dk += (double)native::kBlk;
+          const double e = (double)b.cw * dk;
+          gw[q * native::kBlk + k] = amp * std::exp2(-e * e);
+        }
+      }
+      QI_HIP(hipMalloc((void**)&il.d_gauss_w, gw.size() * sizeof(double)));
+      QI_HIP(hipMemcpy(il.d_gauss_w, gw.data(), gw.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (F64 && demod && !list.empty()) {
       // demodulation tables of the float64 Stockwell bands (exact integer phases, long double): per band exp(-2 pi i idx 256 i / n)
       const long double two_pi = 6.283185307179586476925286766559005768L;

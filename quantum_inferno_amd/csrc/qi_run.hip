@@ -1079,6 +1079,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);
       b.bank = static_cast<const cplx<T>*>(bt.bank);
       b.edge_wq = (int32_t)(p->native_split_e / 512);
+      b.gauss_w = static_cast<const T*>(il.d_gauss_w);
       b.demod_pow = static_cast<const cplx<T>*>(il.d_demod_pow);
       b.demod_t1 = p->d_demod_t1;
       b.demod_t2 = p->d_demod_t2;
