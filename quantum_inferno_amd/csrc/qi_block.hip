@@ -525,7 +525,11 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
           col_p[i + h] += p;
           rowacc += p;
           mx = max_t(mx, p);
-          if (!QI_BDBG(16)) pl += plog2p(p);
+          if constexpr (F64) {  // (the entropy logarithm's table in LDS behind the twiddles -- k_block64 puts it there --, no branch)
+            if (!QI_BDBG(16)) pl += plog2p_flat(p, reinterpret_cast<const double (*)[2]>(tw256 + 256));
+          } else {
+            if (!QI_BDBG(16)) pl += plog2p(p);
+          }
         }
         if (COEF && inside && !QI_BDBG(1)) store_pair(coef_row, tt, z[0], z[1]);
         if (BITS && inside) store_real_pair(bits_row, tt, lg[0], lg[1]);
@@ -1224,7 +1228,8 @@ __device__ __forceinline__ void edge_item(const BlockArgs<T>& a, const BlockItem
     if (time_row && inside) time_row[t] = follows ? time_row[t] + p : p;
     rowacc += p;
     mx = max_t(mx, p);
-    pl += plog2p(p);
+    if constexpr (sizeof(T) == 8) pl += plog2p_flat(p, reinterpret_cast<const double (*)[2]>(tw256 + 256));
+    else pl += plog2p(p);
   }
   const double r0 = wave_max((double)mx), r1 = wave_sum((double)rowacc), r2 = wave_sum((double)pl);
   __syncthreads();  // buf is free
@@ -1378,7 +1383,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
 // float64 records (run_native64): the same band items in double arithmetic -- Gaussian filter spectra in registers, no
 // narrow-spectrum shortcuts (those drop weights below 2^-30 of the peak), no long blocks; split bands through k_block64_edge.  The exchange
 // buffer and the twiddle table take 72 KB of (dynamic) LDS: two workgroups per CU, compiled for two waves per SIMD.
-constexpr size_t kBlk64Lds = (size_t)(kBlkBuf + 256) * sizeof(double2);
+constexpr size_t kBlk64Lds = (size_t)(kBlkBuf + 256 + 128) * sizeof(double2);  // exchange buffer | W256 table | log2 table
 template <bool DEMOD, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a) {
   extern __shared__ __attribute__((aligned(16))) char smem64[];
@@ -1391,6 +1396,7 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a)
     double s, c;
     sincospi((double)tid * (2.0 / 256.0), &s, &c);
     tw256[tid] = make_double2(c, s);
+    if (tid < 128) tw256[256 + tid] = make_double2(kLog2Tab[tid][0], kLog2Tab[tid][1]);  // (block_bands' entropy logarithm)
   }
   double2 w;
   {
@@ -1419,6 +1425,7 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<doubl
   double s, c;
   sincospi((double)tid * (2.0 / 256.0), &s, &c);
   tw256[tid] = make_double2(c, s);
+  if (tid < 128) tw256[256 + tid] = make_double2(kLog2Tab[tid][0], kLog2Tab[tid][1]);
   sincospi((double)col * (2.0 / 4096.0), &s, &c);
   const double2 w = make_double2(c, s);
   const BlockItem it = items[blockIdx.x];

@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       col0[r * kZ64Threads] += p;
       rowacc += p;
       mx = max_t(mx, p);
-      pl += plog2p(p, ltab);
+      pl += plog2p_flat(p, ltab);
     }
     plogp += pl;
     if (a.part_band && !part) {  // (the same for every thread)
