@@ -317,13 +317,13 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 
   // the band descriptor is fetched one band ahead: its load would otherwise sit in front of the filter loads
   BlockBandT<T> bd_next{};
-  if constexpr (!EDGE) bd_next = a.bands[band_first];
+  if constexpr (!EDGE) bd_next = load_uniform(a.bands + band_first);
   for (int jj = 0; jj < band_count; ++jj) {
     BlockBandT<T> bd = bd_next;
     if constexpr (EDGE) {
       bd.out_band = a.edge_band[band_first + jj];
     } else {
-      if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
+      if (jj + 1 < band_count) bd_next = load_uniform(a.bands + band_first + jj + 1);
     }
     cplx<T> v[16];  // (F64: float64 tables hold analytic bands only, none of them `narrow`)
     if (!EDGE && !F64 && bd.narrow == 1) {
@@ -969,10 +969,10 @@ __device__ __forceinline__ void long_bands(const BlockArgs<T>& a, int32_t blk_i,
   double plogp = 0.0;
   const uint32_t tb0 = (uint32_t)(t0 + 2 * (col + 256 * C0));  // first sample of this thread's first kept pair
   int pending = -1, par = 0;
-  BlockBand bd_next = a.bands[band_first];
+  BlockBand bd_next = load_uniform(a.bands + band_first);
   for (int jj = 0; jj < band_count; ++jj) {
     const BlockBand bd = bd_next;
-    if (jj + 1 < band_count) bd_next = a.bands[band_first + jj + 1];
+    if (jj + 1 < band_count) bd_next = load_uniform(a.bands + band_first + jj + 1);
     // this thread's only bin with a weight above 2^-30 of the peak
     const int kres = (col - bd.klo) & 255;
     const int k = (bd.klo + kres) & (kBlk - 1);  // (the band lies in the lower half of the 8192-bin grid)
@@ -1322,9 +1322,9 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_EDGE_WAVES) k_block_edge(B
   const cplx<T> w = mk<T>((T)cs, (T)sn);
   BlockItem it;
   if (items) {
-    it = items[blockIdx.x];
+    it = load_uniform(items + blockIdx.x);
   } else {
-    const DualItem d = dual[blockIdx.x];
+    const DualItem d = load_uniform(dual + blockIdx.x);
     it = BlockItem{d.wq, d.block, d.first0, d.count0, d.plane0, d.slot0};
   }
   switch (-it.wq) {
@@ -1357,7 +1357,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
     sincospif((float)col * (2.0f / 4096.0f), &s, &c);
     w = mk<T>((T)c, (T)s);
   }
-  const BlockItem it = a.items[blockIdx.x];
+  const BlockItem it = load_uniform(a.items + blockIdx.x);
   if (it.wq < 0) {
     // edge item of a split band (styx bank): light items at the end of the list, they fill the tail of the launch
     if constexpr (!DEMOD) {
@@ -1404,7 +1404,7 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64(BlockArgs<double> a)
     sincospi((double)col * (2.0 / 4096.0), &s, &c);
     w = make_double2(c, s);
   }
-  const BlockItem it = a.items[blockIdx.x];
+  const BlockItem it = load_uniform(a.items + blockIdx.x);
   switch (it.wq) {
     case 1: block_item<double, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
     case 2: block_item<double, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
@@ -1428,7 +1428,7 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_block64_edge(BlockArgs<doubl
   if (tid < 128) tw256[256 + tid] = make_double2(kLog2Tab[tid][0], kLog2Tab[tid][1]);
   sincospi((double)col * (2.0 / 4096.0), &s, &c);
   const double2 w = make_double2(c, s);
-  const BlockItem it = items[blockIdx.x];
+  const BlockItem it = load_uniform(items + blockIdx.x);
   switch (-it.wq) {
     case 1: edge_block_item<double, 1, COEF, BITS, PATH>(a, it, buf, tw256, s_red, w); break;
     case 2: edge_block_item<double, 2, COEF, BITS, PATH>(a, it, buf, tw256, s_red, w); break;
@@ -1584,7 +1584,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_LONG_WAVES) k_block_long(B
   const cplx<T> w = mk<T>((T)c, (T)s);
   sincospif((float)col * (2.0f / 8192.0f), &s, &c);
   const cplx<T> w8 = mk<T>((T)c, (T)s);
-  long_item<T, DEMOD, COEF, BITS>(a, items[blockIdx.x], buf, tw256, s_red, w, w8);
+  long_item<T, DEMOD, COEF, BITS>(a, load_uniform(items + blockIdx.x), buf, tw256, s_red, w, w8);
 }
 template <typename T, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kBlkThreads, QI_BLK_LONG_WAVES) k_block_long_dual(BlockArgs<T> a0, BlockArgs<T> a2,
@@ -1601,7 +1601,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_LONG_WAVES) k_block_long_d
   const cplx<T> w = mk<T>((T)c, (T)s);
   sincospif((float)col * (2.0f / 8192.0f), &s, &c);
   const cplx<T> w8 = mk<T>((T)c, (T)s);
-  long_dual_item<T, COEF, BITS>(a0, a2, items[blockIdx.x], buf, tw256, s_red, w, w8);
+  long_dual_item<T, COEF, BITS>(a0, a2, load_uniform(items + blockIdx.x), buf, tw256, s_red, w, w8);
 }
 
 template <typename T, bool COEF, bool BITS>
@@ -1628,7 +1628,7 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
     sincospif((float)col * (2.0f / 4096.0f), &s, &c);
     w = mk<T>((T)c, (T)s);
   }
-  const DualItem it = items[blockIdx.x];
+  const DualItem it = load_uniform(items + blockIdx.x);
 #ifdef QI_NATIVE_STAMPS
   const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();  // (100 MHz) the launch's dispatch timeline
 #endif

@@ -93,6 +93,24 @@ __device__ __forceinline__ qi_cptr<V> as_const(const V* p) {
   return reinterpret_cast<qi_cptr<V>>(reinterpret_cast<uintptr_t>(p));
 }
 
+// A struct at a wave-uniform address (a work item, a band descriptor) by scalar loads: its fields live in scalar registers,
+// not in vector registers of every lane (a band descriptor fetched a band ahead was 24 vector registers of the block kernels).
+// QI_NO_UNIFORM_LOADS: the plain (vector) loads, for A/B.
+template <typename S>
+__device__ __forceinline__ S load_uniform(const S* p) {
+#ifdef QI_NO_UNIFORM_LOADS
+  return *p;
+#else
+  static_assert(sizeof(S) % 4 == 0, "whole dwords");
+  S out;
+  const auto src = as_const(reinterpret_cast<const uint32_t*>(p));
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (size_t i = 0; i < sizeof(S) / 4; ++i) dst[i] = src[i];
+  return out;
+#endif
+}
+
 // streaming stores of panel data that is never read back by this launch (nontemporal: no allocation in the caches)
 typedef float qi_f2 __attribute__((ext_vector_type(2)));
 typedef float qi_f4 __attribute__((ext_vector_type(4)));
