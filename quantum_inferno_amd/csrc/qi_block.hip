@@ -1701,7 +1701,7 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
                                                          cplx<T>* __restrict__ buf, cplx<T>* __restrict__ tw256) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
-  const BandDesc bd = a.bands[a.plane_band[plane_i]];
+  const BandDesc bd = load_uniform(a.bands + *as_const(a.plane_band + plane_i));
   const uint32_t tau1 = plane_i - (uint32_t)bd.edge;
   const int64_t ch = blockIdx.z;
   const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);

@@ -36,7 +36,7 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
 // inside the plane transforms (k_zoom_coarse2g, qi_block.hip).
 template <typename T, bool STX>
 __device__ __forceinline__ void zoom_gather_plane(const ZoomArgs<T>& a, const uint32_t plane) {
-  const BandDesc bd = a.bands[a.plane_band[plane]];  // plane of the record's coarse storage
+  const BandDesc bd = load_uniform(a.bands + *as_const(a.plane_band + plane));  // plane of the record's coarse storage
   const int32_t kappa0 = (int32_t)(blockIdx.x * 256 + threadIdx.x);
   const uint32_t tau1 = plane - (uint32_t)bd.edge;
   const int64_t ch = blockIdx.z;
@@ -57,7 +57,10 @@ __global__ void __launch_bounds__(256) k_zoom_gather2(ZoomArgs<T> a0, ZoomArgs<T
 
 // Fine stage of one level.  PHASOR: multiply by the carrier exp(2 pi i k_c f / Lf) (Gabor banks; the Stockwell bands
 // are at baseband already).  Output sample t is the full-length sample f = t + off, off = 64 A - e (e = 0 or 1).
-template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS>
+// SDESC: the band descriptors by scalar loads (load_uniform: no vector registers for the descriptor fetched a band ahead;
+// -3 % of the interpolation launch at 64 records).  With one or two records a workgroup has few bands and the first
+// descriptor's scalar-cache miss shows (+1 % of the step): those calls keep the vector loads.
+template <typename T, int LEVEL, bool PHASOR, bool COEF, bool BITS, bool SDESC>
 __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int row, double (*s_red)[kZoomThreads / kWave],
                                            double (*s_fin)[kZoomThreads / kWave]) {
   constexpr int NW = kZoomThreads / kWave, S = zoom_span(LEVEL), TAPS = zoom_taps(LEVEL), STEPS = zoom_steps(LEVEL);
@@ -94,7 +97,8 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
   const uint32_t widx2 = (wtau2 & ((1u << plog2) - 1u)) * (uint32_t)kBlk + (wtau2 >> plog2);
   const int jj0 = a.lvl_first[LEVEL] + chunk, jj_end = a.lvl_first[LEVEL] + a.lvl_count[LEVEL];
   cplx<T> smp_next = mk<T>(T(0), T(0)), smq_next = mk<T>(T(0), T(0));
-  BandDesc bd_next = a.bands[jj0 < jj_end ? jj0 : a.lvl_first[LEVEL]];
+  const BandDesc* first_bd = a.bands + (jj0 < jj_end ? jj0 : a.lvl_first[LEVEL]);
+  BandDesc bd_next = SDESC ? load_uniform(first_bd) : *first_bd;
   if (jj0 < jj_end) {
     const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
     smp_next = b[widx];
@@ -104,7 +108,7 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
     const BandDesc bd = bd_next;
     const cplx<T> smp = smp_next, smq = smq_next;
     if (jj + nchunk < jj_end) {
-      bd_next = a.bands[jj + nchunk];
+      bd_next = SDESC ? load_uniform(a.bands + jj + nchunk) : a.bands[jj + nchunk];
       const cplx<T>* __restrict__ b = a.coarse + ((int64_t)ch * a.planes + bd_next.edge) * kBlk;
       smp_next = b[widx];
       if (TWO) smq_next = b[widx2];
@@ -224,16 +228,16 @@ __device__ __forceinline__ void zoom_level(const ZoomArgs<T>& a, int chunk, int 
 }
 
 // row y of a table's fine launch = (level, chunk of the level's band list)
-template <typename T, bool PHASOR, bool COEF, bool BITS>
+template <typename T, bool PHASOR, bool COEF, bool BITS, bool SDESC>
 __device__ __forceinline__ void zoom_row(const ZoomArgs<T>& a, int y, double (*s_red)[kZoomThreads / kWave],
                                          double (*s_fin)[kZoomThreads / kWave]) {
-  if (y < a.lvl_chunk0[0] + a.lvl_nchunk[0]) zoom_level<T, 0, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[0], y, s_red, s_fin);
-  else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[1], y, s_red, s_fin);
-  else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[2], y, s_red, s_fin);
-  else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[3], y, s_red, s_fin);
-  else if (y < a.lvl_chunk0[4] + a.lvl_nchunk[4]) zoom_level<T, 4, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[4], y, s_red, s_fin);
-  else if (y < a.lvl_chunk0[5] + a.lvl_nchunk[5]) zoom_level<T, 5, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[5], y, s_red, s_fin);
-  else zoom_level<T, 6, PHASOR, COEF, BITS>(a, y - a.lvl_chunk0[6], y, s_red, s_fin);
+  if (y < a.lvl_chunk0[0] + a.lvl_nchunk[0]) zoom_level<T, 0, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[0], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[1] + a.lvl_nchunk[1]) zoom_level<T, 1, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[1], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[2] + a.lvl_nchunk[2]) zoom_level<T, 2, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[2], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[3] + a.lvl_nchunk[3]) zoom_level<T, 3, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[3], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[4] + a.lvl_nchunk[4]) zoom_level<T, 4, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[4], y, s_red, s_fin);
+  else if (y < a.lvl_chunk0[5] + a.lvl_nchunk[5]) zoom_level<T, 5, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[5], y, s_red, s_fin);
+  else zoom_level<T, 6, PHASOR, COEF, BITS, SDESC>(a, y - a.lvl_chunk0[6], y, s_red, s_fin);
 }
 
 // one launch for every level: blockIdx.y is the row
@@ -241,16 +245,16 @@ template <typename T, bool PHASOR, bool COEF, bool BITS>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom(ZoomArgs<T> a) {
   __shared__ double s_red[2][kZoomThreads / kWave];
   __shared__ double s_fin[3][kZoomThreads / kWave];
-  zoom_row<T, PHASOR, COEF, BITS>(a, blockIdx.y, s_red, s_fin);
+  zoom_row<T, PHASOR, COEF, BITS, false>(a, blockIdx.y, s_red, s_fin);
 }
 
 // qi_cwt_stx: the rows of the styx table (a0, with carrier) and of the Stockwell table (a2) in one launch
-template <typename T, bool COEF, bool BITS>
+template <typename T, bool COEF, bool BITS, bool SDESC>
 __global__ void __launch_bounds__(kZoomThreads) k_zoom2(ZoomArgs<T> a0, ZoomArgs<T> a2, int rows0) {
   __shared__ double s_red[2][kZoomThreads / kWave];
   __shared__ double s_fin[3][kZoomThreads / kWave];
-  if ((int)blockIdx.y < rows0) zoom_row<T, true, COEF, BITS>(a0, blockIdx.y, s_red, s_fin);
-  else zoom_row<T, false, COEF, BITS>(a2, (int)blockIdx.y - rows0, s_red, s_fin);
+  if ((int)blockIdx.y < rows0) zoom_row<T, true, COEF, BITS, SDESC>(a0, blockIdx.y, s_red, s_fin);
+  else zoom_row<T, false, COEF, BITS, SDESC>(a2, (int)blockIdx.y - rows0, s_red, s_fin);
 }
 
 template <typename T, bool PHASOR>
@@ -335,10 +339,17 @@ int launch_zoom2<float>(const ZoomArgs<float>& a0, const ZoomArgs<float>& a2, in
     return QI_ERR_STATE;
   }
   dim3 grid((unsigned)(g0 > g2 ? g0 : g2), (unsigned)(r0 + r2), (unsigned)n_channels);
-  if (coef && bits) k_zoom2<float, true, true><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
-  else if (coef) k_zoom2<float, true, false><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
-  else if (bits) k_zoom2<float, false, true><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
-  else k_zoom2<float, false, false><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);
+  const bool sdesc = n_channels >= 4;  // (see zoom_level)
+#define QI_ZOOM2(C, B)                                                                  \
+  do {                                                                                  \
+    if (sdesc) k_zoom2<float, C, B, true><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);   \
+    else k_zoom2<float, C, B, false><<<grid, kZoomThreads, 0, st>>>(a0, a2, r0);        \
+  } while (0)
+  if (coef && bits) QI_ZOOM2(true, true);
+  else if (coef) QI_ZOOM2(true, false);
+  else if (bits) QI_ZOOM2(false, true);
+  else QI_ZOOM2(false, false);
+#undef QI_ZOOM2
   QI_LAUNCH_CHECK();
   return QI_OK;
 }

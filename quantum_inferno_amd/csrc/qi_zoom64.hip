@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
   for (int r = 0; r < R; ++r) col0[r * kZ64Threads] = 0.0;
   double mx = 0.0, plogp = 0.0;
   for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
-    const BandDesc bd = a.bands[jj];
+    const BandDesc bd = load_uniform(a.bands + jj);
     const cd* __restrict__ C = a.Z + ((int64_t)ch * a.nbands + jj) * (a.M + 2 * kZ64Pad) + kZ64Pad;
     __syncthreads();  // the previous band's readers are done with the window (and with s_red)
     for (int i = tid; i < nwin; i += kZ64Threads) win[i] = C[(m_first + (uint32_t)i) & mmask];
