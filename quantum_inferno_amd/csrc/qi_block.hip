@@ -1537,9 +1537,10 @@ __global__ void __launch_bounds__(kBlkThreads, 2) k_z64_coarse(Z64Args a) {
   const int32_t P = (int32_t)(a.M / kBlk);
   // Consecutive workgroups go to consecutive XCDs; the P planes of a band fill the same 128-byte lines of its coarse array
   // (sample tau = P tau2 + tau1, 16 bytes each) and gather the same bins: consecutive planes sit behind ONE L2 -- workgroup
-  // w takes plane (w mod 8) (planes / 8) + w / 8 of the launch (planes = bands x P is a multiple of 8)
+  // w takes plane (w mod 8) ceil(planes / 8) + w / 8 of the launch (the grid is rounded up to a multiple of 8)
   const uint32_t planes = (uint32_t)a.nbands * (uint32_t)P;
-  const uint32_t pi = (blockIdx.x & 7u) * (planes >> 3) + (blockIdx.x >> 3);
+  const uint32_t pi = (blockIdx.x & 7u) * ((planes + 7u) >> 3) + (blockIdx.x >> 3);
+  if (pi >= planes) return;  // (the same for the whole workgroup)
   const uint32_t band = pi / (uint32_t)P, tau1 = pi - band * (uint32_t)P;
   const BandDesc bd = a.bands[band];
   const int64_t ch = blockIdx.y;
@@ -2026,11 +2027,11 @@ int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channe
 int launch_z64_coarse(const Z64Args& a, int64_t n_channels, hipStream_t st) {
   if (a.nbands <= 0) return QI_OK;
   const int64_t P = a.M / kBlk;
-  if (P < 8 || P * kBlk != a.M || (a.M & (a.M - 1)) != 0) {
+  if (P < 1 || P * kBlk != a.M || (a.M & (a.M - 1)) != 0) {
     set_error("float64 zoom: a coarse grid of %lld samples has no in-LDS coarse stage", (long long)a.M);
     return QI_ERR_UNSUPPORTED;
   }
-  dim3 grid((unsigned)(a.nbands * P), (unsigned)n_channels, 1);
+  dim3 grid((unsigned)(8 * ceil_div(a.nbands * P, 8)), (unsigned)n_channels, 1);
   if (a.kind == 2) {
     QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_z64_coarse<true>), kBlk64Lds));
     k_z64_coarse<true><<<grid, kBlkThreads, kBlk64Lds, st>>>(a);

@@ -312,7 +312,7 @@ struct Z64Args {
 int launch_z64_gather(const Z64Args& a, int64_t n_channels, hipStream_t st);
 int launch_z64_interp(const Z64Args& a, int nchunk, int64_t n_channels, hipStream_t st);
 int launch_z64_pad(cplx<double>* Z, int64_t M, int64_t rows, hipStream_t st);  // fills the pads of `rows` coarse arrays
-// gather + M-point transform + pads of one level in ONE launch of 4096-point plane transforms in LDS (qi_block.hip; M >= 8 x 4096)
+// gather + M-point transform + pads of one level in ONE launch of 4096-point plane transforms in LDS (qi_block.hip; M >= 4096)
 int launch_z64_coarse(const Z64Args& a, int64_t n_channels, hipStream_t st);
 void z64_weights(int log2d, double* w /*[1 << log2d][kZ64Taps]*/);
 

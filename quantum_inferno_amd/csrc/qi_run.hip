@@ -1026,7 +1026,7 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       z.power_scale = power_scale;
       z.eps = eps;
       p->prof.begin(st, QI_STAGE_ZOOM_COARSE);
-      if (g < p->native_z64_coarse && z.M >= 8 * native::kBlk) {  // the coarsest grids: gather, transform and pads in one launch
+      if (g < p->native_z64_coarse && z.M >= native::kBlk) {  // the coarsest grids: gather, transform and pads in one launch
         QI_TRY(native::launch_z64_coarse(z, ct, st));
       } else {
         QI_TRY(native::launch_z64_gather(z, ct, st));
