@@ -164,8 +164,6 @@ class StreamPipeline:
         self._stage(0, mine[0])
         for k, item in enumerate(mine):
             j = k & 1
-            if k + 1 < len(mine):
-                self._stage(j ^ 1, mine[k + 1])  # next item's gather + copy overlap this item's transforms
             c0, cb, chunk, s = item
             if self._gpu:
                 compute.wait_event(self._copied[j])
@@ -184,6 +182,11 @@ class StreamPipeline:
                     res[t] = self._out[key]
             if self._gpu:
                 self._consumed[j].record(compute)
+            # the next item's host gather (a 134 MB memcpy at 16 float64 records: milliseconds of host time) and its copy to
+            # the device run AFTER this item's launches are queued: they overlap its transforms even when the consumer
+            # waits for every item before asking for the next (round 3 staged first: the GPU idled through the gather)
+            if k + 1 < len(mine):
+                self._stage(j ^ 1, mine[k + 1])
             kept = {t: self._keep(r) for t, r in res.items()}
             yield StreamItem(first_item + k, c0, cb, chunk, s, kept.get("cwt"), kept.get("stx"))
 
