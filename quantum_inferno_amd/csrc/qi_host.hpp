@@ -347,7 +347,9 @@ struct qi_plan {
   bool capturing = false;   // inside the capture of a qi_cwt_stx call: the fork to the side stream was recorded at its start
   int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
                            // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
-                           // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option
+                           // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option.
+                           // 3: the fork as early as in a captured call, 4 / 5: the side stream at the lowest / highest priority
+                           // (round 4, one record: 0.2552 / 0.2572 / 0.2633 ms against 0.2460 serial)
   int native_z64 = 1;      // float64: narrow-spectrum bands at the decimated rate (coarse inverse FFT + 16-tap interpolation)
   int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
   double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level

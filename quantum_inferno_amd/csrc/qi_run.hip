@@ -460,11 +460,17 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
                            (finish->blk.coef != nullptr) == (out->coef != nullptr) &&
                            (finish->blk.bits != nullptr) == (out->bits != nullptr);
     const bool pair = joint_blk && (p->native_pair || p->capturing) && !overlap;
-    if (pair && !p->side) {
-      QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    // (native_pair >= 3: the fork as early as in a captured call; 4: the side stream at the lowest priority, so that the
+    // small launches of the other branch get the workgroup slots the block launch frees)
+    const bool early = p->capturing || p->native_pair >= 3;
+    if ((pair || (early && deferring)) && !p->side) {
+      int least = 0, greatest = 0;
+      if (p->native_pair >= 4) QI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      QI_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, p->native_pair == 5 ? greatest : least));
       QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
       QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     }
+    if (early && !p->ev_parts) QI_HIP(hipEventCreateWithFlags(&p->ev_parts, hipEventDisableTiming));
     auto launch_blocks = [&](hipStream_t bs, int phase = 0) -> int {  // phase 1: band items only, 2: edge items only (joint launch)
       native::BlockArgs<T> b{};
       b.n = n;
@@ -529,9 +535,9 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     // clearing of BOTH tables' partial sums and nothing else -- the fork is recorded in the first (styx) run behind its
     // clearing; the second run clears its partials on the side stream in front of the block launch and lets its own stream
     // wait for just that.
-    const bool cap_pair = pair && p->capturing;
+    const bool cap_pair = pair && early;
     if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, cap_pair ? p->side : st));
-    if (p->capturing && deferring && c0 == 0) {
+    if (early && deferring && c0 == 0) {
       QI_HIP(hipEventRecord(p->ev_fork, st));
       QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
     }
