@@ -947,21 +947,21 @@ int launch_pass1<double>(const RowArgs<double>& a, int kind, int64_t n_channels,
 }
 
 // forward transform of n_channels real records (a.sig) into Xout [C][Lf], through a.imd (one slot per channel)
-template <class C1>
-static int launch_forward_cfg(const RowArgs<float>& a0, float2* Xout, int64_t n_channels, hipStream_t st) {
+template <typename T, class C1>
+static int launch_forward_cfg(const RowArgs<T>& a0, cplx<T>* Xout, int64_t n_channels, hipStream_t st) {
   using C2 = C1;
-  RowArgs<float> a = a0;
+  RowArgs<T> a = a0;
   a.phase_split = a.N1 == 2048 && (a.N2 / C1::G) * n_channels < 256 ? 1 : 0;
   dim3 g1((unsigned)(a.N2 / C1::G), a.phase_split ? 2u : 1u, (unsigned)n_channels);
   if (a.N1 == 1024)
-    QI_TRY((launch_p1<float, C1, 2, 1>(a, g1, st)));
+    QI_TRY((launch_p1<T, C1, 2, 1>(a, g1, st)));
   else if (a.N1 == 2048)
-    QI_TRY((launch_p1<float, C1, 2, 2>(a, g1, st)));
+    QI_TRY((launch_p1<T, C1, 2, 2>(a, g1, st)));
   else {
     set_error("native forward transform supports N1 = 1024 or 2048, got %lld", (long long)a.N1);
     return QI_ERR_UNSUPPORTED;
   }
-  auto kern = k_fwd2<float, C2>;
+  auto kern = k_fwd2<T, C2>;
   QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(kern), C2::LDS_BYTES));
   dim3 g2((unsigned)(a.N1 / C2::G), 1, (unsigned)n_channels);
   kern<<<g2, C2::TH, C2::LDS_BYTES, st>>>(a, Xout);
@@ -971,8 +971,13 @@ static int launch_forward_cfg(const RowArgs<float>& a0, float2* Xout, int64_t n_
 template <>
 int launch_forward<float>(const RowArgs<float>& a, float2* Xout, int64_t n_channels, hipStream_t st) {
   // few records: 8-row workgroups, twice as many of them (a launch of 16-row workgroups would leave most CUs idle)
-  if (n_channels * (a.N2 / 16) < 256) return launch_forward_cfg<Cfg<float, 8>>(a, Xout, n_channels, st);
-  return launch_forward_cfg<Cfg<float, 16>>(a, Xout, n_channels, st);
+  if (n_channels * (a.N2 / 16) < 256) return launch_forward_cfg<float, Cfg<float, 8>>(a, Xout, n_channels, st);
+  return launch_forward_cfg<float, Cfg<float, 16>>(a, Xout, n_channels, st);
+}
+// float64 (round 4): the same two launches in double instead of hipFFT's five passes over the padded records
+template <>
+int launch_forward<double>(const RowArgs<double>& a, double2* Xout, int64_t n_channels, hipStream_t st) {
+  return launch_forward_cfg<double, Cfg<double, 8>>(a, Xout, n_channels, st);
 }
 
 template <typename T, class C>

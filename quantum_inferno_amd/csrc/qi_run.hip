@@ -898,6 +898,10 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr, want_time = out->power_time != nullptr;
   const bool time_via_part = want_time && (chunk_total > 1 || shorts);
   const int64_t nbk = nblk + (shorts ? 1 : 0);  // partial slots per band (last one: the corrected edge samples)
+  // forward transform of the records: the two-pass kernels in double where they exist (2^20- and 2^21-point transforms),
+  // staged through one slot of the intermediate; hipFFT elsewhere
+  const bool fwd_native = p->native_fwd && native_len_ok(Lf);
+  if (fwd_native && imd_elems < Lf) imd_elems = Lf;
   const size_t e_x = (size_t)Lf * sizeof(cplx<T>);
   const size_t e_xn = shorts ? (size_t)n * sizeof(cplx<T>) : 0;
   const size_t e_imd = (size_t)imd_elems * sizeof(cplx<T>);
@@ -938,8 +942,22 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
     if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.begin(st, QI_STAGE_FORWARD);
-    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
-    QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    if (fwd_native) {
+      native::RowArgs<T> f{};
+      f.Lf = Lf;
+      f.n = n;
+      f.N1 = Lf / native::kN2;
+      f.N2 = native::kN2;
+      f.imd_slots = 1;
+      f.imd = imd;
+      f.sig = sig + c0 * n;
+      f.two_over_len = (float)(2.0 / (double)Lf);
+      f.debug = 0;
+      QI_TRY(native::launch_forward<T>(f, X, ct, st));
+    } else {
+      QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, Lf, st));
+      QI_TRY(fft_c2c<T>(p->fft, X, Lf, ct, HIPFFT_FORWARD, st));
+    }
     if (shorts) QI_TRY(native::launch_even_bins<T>(X, Xn, ct, n, st));
     p->prof.end(QI_STAGE_FORWARD, st);
     cplx<T>* coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
