@@ -42,15 +42,9 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   // scipy.signal.fftconvolve pads to next_fast_len(2n-1) (= 2n when n = 2^k); any L >= 2n-1 gives the
   // same linear correlation, so other n use the next power of two.
   p->L = is_pow2(desc->n) ? 2 * desc->n : next_pow2(2 * desc->n - 1);
-  if (const char* e = tune_env("QI_NATIVE_KMAX")) {
-    const long v = atol(e);
-    if (v >= 0) p->native_kmax = v;
-  }
   if (p->native_kmax > (int64_t)native::kMaxPrunedTerms * native::kN2)
     p->native_kmax = (int64_t)native::kMaxPrunedTerms * native::kN2;
   if (const char* e = tune_env("QI_NATIVE_DEBUG")) p->native_debug = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_GROUP")) p->native_group = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_WGS")) p->native_wgs = atoi(e) > 0 ? atoi(e) : 256;
   if (const char* e = tune_env("QI_NATIVE_FWD")) p->native_fwd = atoi(e);
 #ifdef QI_NATIVE_STAMPS
   if (tune_env("QI_NATIVE_STAMPS")) {
@@ -64,49 +58,20 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_ZOOM_SHORT")) p->native_zoom_short = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_ZOOM_SHORT_FROM")) p->native_zoom_short_from = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS")) p->native_zoom_wgs = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_ZOOM_WGS_JOINT")) p->native_zoom_wgs_joint = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_ZOOM_WAVES")) p->native_zoom_waves = atoi(e) > 0 ? atoi(e) : p->native_zoom_waves;
-  if (const char* e = tune_env("QI_NATIVE_BLK_ANALYTIC")) p->native_blk_analytic = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_OVERLAP")) p->native_overlap = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_PAIR")) p->native_pair = atoi(e);
   p->native_graph = (desc->flags & QI_PLAN_GRAPH) ? 1 : 0;
   if (const char* e = tune_env("QI_NATIVE_GRAPH")) p->native_graph = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_GATHER_FUSED")) p->native_gather_fused = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_SPLIT_E")) p->native_split_e = atoll(e);
   if (const char* e = tune_env("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_NARROW")) p->native_blk_narrow = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_TAIL")) p->native_tail = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_TILE")) p->native_tile = atoll(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_MAXWQ")) p->native_blk_maxwq = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_BANDS")) p->native_blk_bands = atoi(e) > 0 ? atoi(e) : p->native_blk_bands;
-  if (const char* e = tune_env("QI_NATIVE_BLK_BANDS_BATCH")) p->native_blk_bands_batch = atoi(e) > 0 ? atoi(e) : p->native_blk_bands_batch;
-  if (const char* e = tune_env("QI_NATIVE_BLK_BATCH_FROM")) p->native_blk_batch_from = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_HALF")) p->native_blk_half = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_LONG")) p->native_blk_long = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_EDGE_MERGE")) p->native_edge_merge = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_BLK_FASTW")) p->native_blk_fastw = atoi(e);
 #ifdef QI_BLK_LZ
   if (const char* e = tune_env("QI_NATIVE_BLK_LZ")) p->native_blk_lz = atoi(e);
 #endif
-  if (const char* e = tune_env("QI_NATIVE_ROWS")) {
-    const long v = atol(e);
-    if (v == 8 || v == 16) p->native_rows = (int)v;
-  }
   if (const char* e = tune_env("QI_NATIVE_F64")) p->native_f64 = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64")) p->native_z64 = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_FINE")) p->native_z64_fine = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_Z64_ROWS")) p->native_z64_rows = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_COARSE")) p->native_z64_coarse = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_BLOCK_FROM")) p->native_z64_block_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK64_WTAB")) p->native_blk64_wtab = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_Z64_LEVELS")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= native::kZ64Levels) p->native_z64_levels = v;
-  }
   if (desc->dtype == QI_F64) {  // the float32 zoom / block / split engines are sized for the float32 tolerance
     const int short64 = p->native_short && !(tune_env("QI_NATIVE_SHORT64") && atoi(tune_env("QI_NATIVE_SHORT64")) == 0);
     // (the block engine runs float64 tables in double arithmetic: analytic Gaussian bands, no narrow-spectrum shortcuts)
@@ -118,7 +83,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
     p->native_split = split64;
     // (a longer taper than the float32 engines': the tapered spectrum is half as wide at the 2^-50 level the float64 zoom
     // keeps -- a coarser grid for every split band; measured 10.03 against 10.29 ms at order 12 x 4 records)
-    if (!tune_env("QI_NATIVE_SPLIT_E")) p->native_split_e = 2048;
+    p->native_split_e = 2048;
     p->native_block = block64;
     p->native_short = short64;  // wide-spectrum, short-atom styx bands as circular correlations of length n + edge fix
     p->native_rows = 8;

@@ -2098,8 +2098,7 @@ int launch_zoom_coarse_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<
   }
   dim3 grid((unsigned)(((a0.planes + a2.planes) + 63) / 64 * 64), 1, (unsigned)n_channels);
   // few records: a couple of workgroups per CU, each waiting on its loads -- twice as many in flight
-  static const int nf_forced = tune_env("QI_NATIVE_COARSE_NF") ? atoi(tune_env("QI_NATIVE_COARSE_NF")) : 0;
-  if (nf_forced == 8 || (nf_forced != 16 && n_channels > 2)) k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
+  if (n_channels > 2) k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   else k_zoom_coarse2g<float, 16><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;

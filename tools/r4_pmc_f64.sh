@@ -12,7 +12,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_SMEM SQ_ACTIVE_INST_LD
 echo "pass b rc=$?"
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py k_z64,k_block64 $out/a $out/b > $out/sq_counters.txt
-QI_NATIVE_VERBOSE=1 python -c "
+QI_TUNE=1 QI_NATIVE_VERBOSE=1 python -c "
 import torch, numpy as np
 import quantum_inferno_amd as qi
 n, fs, order = 1 << 20, 1000.0, 12
