@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import relmax
+from conftest import ROOT, relmax
 from oracle import tfr_oracle as orc
 
 import quantum_inferno_amd as qi
@@ -121,6 +121,43 @@ def test_stft_benchmark_shape_vs_reference(golden, dtype):
     assert np.max(np.abs(z[:, cols] - g[f"z_cols_{dtype}"])) <= tol * zmax
     big = np.abs(g[f"z_cols_{dtype}"]) >= 1e-3 * zmax
     assert np.max(np.abs(bits[:, cols] - g[f"bits_cols_{dtype}"])[big]) <= (2e-3 if dtype == "float32" else 1e-8)
+
+
+def test_stft_split_kernel_vs_reference(golden):
+    """k_stft_split (the 2048-point transform split by bin parity, a development switch: QI_STFT_SPLIT=1) against the same
+    reference rows and columns as the product kernel, in a process of its own (the switches are read once per process)."""
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import tfr_oracle as orc
+from quantum_inferno_amd import styx_fft
+g = np.load(%r)
+n, fs, order = 1 << 20, 1000.0, 12
+sig = orc.synth_chirp(n, fs, dtype=np.float32)
+z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
+rows, cols = g["rows_float32"], g["cols_float32"]
+zmax = float(g["zmax_float32"])
+e1 = float(np.max(np.abs(z[rows] - g["z_rows_float32"])) / zmax)
+e2 = float(np.max(np.abs(z[:, cols] - g["z_cols_float32"])) / zmax)
+big = np.abs(g["z_cols_float32"]) >= 1e-3 * zmax
+e3 = float(np.max(np.abs(bits[:, cols] - g["bits_cols_float32"])[big]))
+import hashlib
+print("SPLIT", z.shape[0], z.shape[1], e1, e2, e3, hashlib.sha1(np.ascontiguousarray(z).tobytes()).hexdigest())
+""" % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden", "stft_n1048576_o12.npz"))
+    env = dict(os.environ, QI_TUNE="1", QI_STFT_SPLIT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("SPLIT")][-1].split()
+    assert (int(line[1]), int(line[2])) == (1025, 1025)
+    assert float(line[3]) <= 2e-6 and float(line[4]) <= 2e-6 and float(line[5]) <= 2e-3
+    # (the other kernel did run: its roundings differ from the product kernel's)
+    import hashlib
+
+    z0 = styx_fft.stft_from_sig(orc.synth_chirp(1 << 20, 1000.0, dtype=np.float32), 1000.0, 12)[0]
+    assert hashlib.sha1(np.ascontiguousarray(z0).tobytes()).hexdigest() != line[6]
 
 
 def test_stft_2d_batch_and_errors(golden):
