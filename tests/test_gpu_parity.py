@@ -906,7 +906,8 @@ def test_welch_vs_reference(golden, dtype):
 def test_native_engines_other_band_tables(order, fs):
     """Band tables with other populations of the three native sub-engines (zoom classes, block reach groups, two-pass)
     than the benchmark's order 3: the native engine against the hipFFT engine on the same noise + chirp record,
-    n = 2^20, coefficients, bits and every fused reduction; per-band power also as a direct sum of the stored panel."""
+    n = 2^20, coefficients, bits and every fused reduction; per-band power also as a direct sum of the stored panel; nine
+    bands spread over each table against the oracle."""
     from quantum_inferno_amd import _lib
 
     n = 1 << 20
@@ -933,6 +934,12 @@ def test_native_engines_other_band_tables(order, fs):
         assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
         direct = (a.coef.abs().double() ** 2).sum(dim=2)
         assert torch.allclose(a.power_band, direct, rtol=1e-5, atol=1e-9 * float(direct.max()))
+        # ... and against the ORACLE on bands spread over the table (every engine's share of it)
+        pick = sorted({0, 1, nb // 5, (2 * nb) // 5, nb // 2, (3 * nb) // 5, (4 * nb) // 5, nb - 2, nb - 1})
+        _, _, want = (orc.cwt_fft if name == "cwt" else orc.stx_fft)(order, x[0].astype(np.float64), fs, bands=pick)
+        got = a.coef[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        for i, j in enumerate(pick):
+            assert np.max(np.abs(got[i] - want[i])) <= 2e-5 * np.max(np.abs(want[i])), (name, order, j)
         del a, b
     nat.close()
     ref.close()
@@ -1141,7 +1148,8 @@ def test_fused_call_other_requests_and_tiles():
 def test_native_engine_other_lengths(log2n, order):
     """Stockwell transform and styx CWT at the other power-of-two lengths the native engine takes (their order-3 band
     tables need only the zoom and block engines -- the CWT's longest atoms as split bands -- which are not tied to the
-    two-pass kernels' 2^20 / 2^21) against the hipFFT engine: every row, the fused reductions, and the fused call."""
+    two-pass kernels' 2^20 / 2^21) against the hipFFT engine: every row, the fused reductions, and the fused call; seven
+    bands of each table (split / zoom / block engine) against the oracle."""
     from quantum_inferno_amd import _lib
 
     n, fs = 1 << log2n, 1000.0
@@ -1165,6 +1173,14 @@ def test_native_engine_other_lengths(log2n, order):
         assert torch.allclose(a.power_band, b.power_band, rtol=1e-4, atol=1e-9 * float(b.power_band.max()))
         assert torch.allclose(a.power_time, b.power_time, rtol=1e-3, atol=1e-6 * float(b.power_time.max()))
         assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-4)
+        # ... and against the ORACLE (float64 arithmetic on the same float32 record) on bands of every engine: the
+        # lowest (split / zoom), the middle (zoom) and the highest (block) of the table
+        pick = sorted({0, 1, nb // 3, nb // 2, (2 * nb) // 3, nb - 2, nb - 1})
+        _, _, want = (orc.cwt_fft if name == "cwt" else orc.stx_fft)(order, x[0].cpu().numpy().astype(np.float64), fs, bands=pick)
+        got = a.coef[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        for i, j in enumerate(pick):
+            assert np.max(np.abs(got[i] - want[i])) <= 2e-5 * np.max(np.abs(want[i])), (log2n, name, j)
+        assert np.allclose(a.power_band[0][torch.tensor(pick, device="cuda")].cpu().numpy(), (np.abs(want) ** 2).sum(axis=1), rtol=2e-4)
         if not knobs:
             assert nat.stage_bands("zoom")[which] + nat.stage_bands("block")[which] == nb  # the native engine did run
         if name == "cwt":
