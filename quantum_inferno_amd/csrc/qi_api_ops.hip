@@ -85,6 +85,11 @@ int sliding_istft_impl(int device, const cplx<T>* S, int64_t C, const T* dual, i
                        int64_t first, int64_t nseg, int64_t roll, int64_t k0, int64_t k1, T* out, char* scratch,
                        hipStream_t st) {
   const int64_t nf = nfft / 2 + 1;
+  static const bool fused_off = tune_env("QI_STFT_FUSED") && atoi(tune_env("QI_STFT_FUSED")) == 0;
+  if (!fused_off) {  // one kernel: fold, inverse transform in LDS, overlap-add in gather form
+    const int rc = launch_istft_fused<T>(S, dual, out, C, seg, hop, nfft, first, nseg, roll, k0, k1, st);
+    if (rc != QI_ERR_UNSUPPORTED) return rc;  // (other transform lengths, or a device without the LDS: the three-kernel path)
+  }
   T* slices = reinterpret_cast<T*>(scratch);
   cplx<T>* F = reinterpret_cast<cplx<T>*>(scratch + align_up((size_t)C * nseg * nfft * sizeof(T)));
   QI_TRY(launch_sliding_untranspose<T>(S, F, C, nseg, nf, st));

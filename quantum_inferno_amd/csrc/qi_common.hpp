@@ -169,6 +169,10 @@ template <typename T>
 int launch_stft_fused(const T* sig, const T* win, cplx<T>* Z, T* bits, int64_t C, int64_t n, int64_t seg, int64_t hop,
                       int64_t nfft, int64_t nseg, int64_t lead, double scale, double eps, hipStream_t st,
                       double* welch_part = nullptr, const StftSliding* sliding = nullptr);
+// fused inverse of the ShortTimeFFT-convention transform (QI_ERR_UNSUPPORTED, with no error text, where it does not apply)
+template <typename T>
+int launch_istft_fused(const cplx<T>* S, const T* dual, T* out, int64_t C, int64_t seg, int64_t hop, int64_t nfft, int64_t first,
+                       int64_t nseg, int64_t roll, int64_t k0, int64_t k1, hipStream_t st);
 // Welch mean on the fused kernel (`part`: [C][<= nseg][nfft / 2 + 1] doubles of scratch)
 template <typename T>
 int launch_welch_fused(const T* sig, const T* win, T* pxx, double* part, int64_t C, int64_t n, int64_t seg, int64_t hop,

@@ -555,6 +555,136 @@ __global__ void __launch_bounds__(kStftThreads) k_stft_split(const T* __restrict
   }
 }
 
+// Inverse of the ShortTimeFFT-convention transform (qi_sliding_istft; ref utilities/short_time_fft.py:106-137, scipy's
+// ShortTimeFFT.istft) in ONE kernel instead of un-transpose -> batched C2R FFT -> overlap-add (round 4).  A workgroup owns
+// GOWN consecutive hops of the output and holds the GOWN + H slices that cover them (H = ceil(seg / hop) - 1 slices of the
+// previous workgroup's range are transformed again: the gather form of the overlap-add, no atomics, fixed order).  Per
+// slice: the one-sided spectrum X[0..M] (M = nfft / 2; the imaginary parts of X[0] and X[M] are dropped as irfft does)
+// is folded into the M complex numbers Z'[k] = A[k] + i B[k], A[k] = X[k] + conj X[M - k], B[k] = (X[k] - conj X[M - k])
+// exp(+i pi k / M), whose unnormalised inverse M-point transform is x[2 m] + i x[2 m + 1] -- the mirror image of the forward
+// kernel's untangling, same four-step transform in LDS with the conjugate twiddles.  Output sample k = the sum over its
+// slices q of x_q[(k - first - q hop - roll) mod nfft] dual[k - first - q hop], times 1 / nfft.
+struct IstftArgs {
+  int64_t seg, hop, nseg, first, roll, k0, k1;
+  int32_t gown, halo, ngroups, log2gp;  // log2gp: log2 of the slice count of a workgroup rounded up to a power of two
+  int32_t per_xcd;                      // work items (record, group) per XCD
+  int64_t nitems;
+};
+template <typename T, int LOG2R, int LOG2C>
+__global__ void __launch_bounds__(kStftThreads) k_istft_fused(const cplx<T>* __restrict__ S, const T* __restrict__ dual,
+                                                              const cplx<T>* __restrict__ twg, T* __restrict__ out, IstftArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  constexpr int R = 1 << LOG2R, C = 1 << LOG2C, M = R * C, RS = C + 1, TILE = R * RS + 1;
+  const int G = a.gown + a.halo;
+  cplx<T>* __restrict__ data = reinterpret_cast<cplx<T>*>(lds_raw);
+  cplx<T>* __restrict__ tw = data + (size_t)G * TILE;
+  const int tid = threadIdx.x;
+  // XCD-aware mapping as in k_stft_fused: every XCD takes a contiguous range of the (record, group) items, so that the 56- /
+  // 64-byte pieces of neighbouring groups, which share 128-byte lines of a frequency row, meet in one L2
+  const int64_t item = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= a.per_xcd || item >= a.nitems) return;
+  const int64_t c = item / a.ngroups, nf = M + 1;
+  const int64_t m_own = (item % a.ngroups) * a.gown, m_lo = m_own - a.halo;  // slices m_lo .. m_lo + G - 1 (some may not exist)
+  for (int k = tid; k <= M; k += kStftThreads) tw[k] = twg[k];
+  // fold: thread = (bin pair (k, M - k), slice): consecutive threads read consecutive slices of a frequency row
+  // (slices along the low bits of the thread index, padded to a power of two: no division by G)
+  const int lgp = a.log2gp, g = tid & ((1 << lgp) - 1);
+  const int64_t m = m_lo + g;
+  const bool live = g < G && m >= 0 && m < a.nseg;
+  const cplx<T>* __restrict__ Sa = S + c * nf * a.nseg + m;
+  // (the loads of UN sweeps are issued before any of them is used: the loop is bound by their latency)
+  constexpr int UN = sizeof(T) == 4 ? 8 : 4;
+  const int kstep = kStftThreads >> lgp;
+  cplx<T>* __restrict__ dg = data + (size_t)g * TILE;
+  for (int kb0 = tid >> lgp; g < G && kb0 <= M / 2; kb0 += UN * kstep) {
+    cplx<T> xa[UN], xb[UN], wk[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = kb0 + u * kstep;
+      const bool on = live && k <= M / 2;
+      xa[u] = on ? Sa[(int64_t)k * a.nseg] : mk<T>(T(0), T(0));
+      xb[u] = on ? Sa[(int64_t)(M - k) * a.nseg] : mk<T>(T(0), T(0));
+      wk[u] = twg[k <= M / 2 ? k : 0];  // exp(-i pi k / M): B = D conj(w)
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = kb0 + u * kstep;
+      if (k > M / 2) break;
+      if (k == 0) {
+        xa[u].y = T(0);
+        xb[u].y = T(0);
+      }
+      const cplx<T> w = wk[u];
+      const cplx<T> A = mk<T>(xa[u].x + xb[u].x, xa[u].y - xb[u].y), D = mk<T>(xa[u].x - xb[u].x, xa[u].y + xb[u].y);
+      const cplx<T> B = mk<T>(D.x * w.x + D.y * w.y, D.y * w.x - D.x * w.y);
+      dg[(k >> LOG2C) * RS + (k & (C - 1))] = mk<T>(A.x - B.y, A.y + B.x);  // A + i B
+      if (k > 0 && 2 * k != M) {
+        const int kb = M - k;
+        dg[(kb >> LOG2C) * RS + (kb & (C - 1))] = mk<T>(A.x + B.y, B.x - A.y);  // conj(A - i B)
+      }
+    }
+  }
+  __syncthreads();
+  // step 1: columns (inverse sign: conjugate twiddles)
+  for (int q = tid; q < G * C; q += kStftThreads) {
+    const int g = q >> LOG2C, cc = q & (C - 1);
+    cplx<T>* __restrict__ d = data + (size_t)g * TILE + cc;
+    cplx<T> v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = d[r * RS];
+    native::fft_reg<T, R, 1>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) {
+      cplx<T> y = v[native::brev(k1, LOG2R)];
+      if (k1 > 0) {
+        const int j2 = 2 * cc * k1;
+        const cplx<T> w = tw[j2 & (M - 1)];
+        y = cmul(y, (j2 & M) ? mk<T>(-w.x, w.y) : mk<T>(w.x, -w.y));
+      }
+      d[k1 * RS] = y;
+    }
+  }
+  __syncthreads();
+  // step 2: rows; row k1, column k2 then holds the pair e = k1 + R k2: (x[2 e], x[2 e + 1])
+  for (int q = tid; q < G * R; q += kStftThreads) {
+    const int g = q >> LOG2R, k1 = q & (R - 1);
+    cplx<T>* __restrict__ d = data + (size_t)g * TILE + k1 * RS;
+    cplx<T> v[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) v[j] = d[j];
+    native::fft_reg<T, C, 1>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < C; ++k2) d[k2] = v[native::brev(k2, LOG2C)];
+  }
+  __syncthreads();
+  // overlap-add of the owned hops: sample k' = k - first in [m_own hop, (m_own + gown) hop)
+  // (hop by hop, sample j of hop h: its slices are q = m_own + h, m_own + h - 1, ... at offsets i = j, j + hop, ... < seg, in
+  // ascending q like the three-kernel path -- no division)
+  const T inv = T(1) / (T)(2 * M);
+  const T* __restrict__ flat = reinterpret_cast<const T*>(data);
+  const int hop = (int)a.hop, seg = (int)a.seg, roll = (int)a.roll;
+  for (int h = 0; h < a.gown; ++h) {
+    const int64_t qh = m_own + h;
+    for (int j = tid; j < hop; j += kStftThreads) {
+      const int64_t k = qh * a.hop + j + a.first;
+      if (k < a.k0 || k >= a.k1) continue;
+      int dmax = (seg - 1 - j) / hop;  // slices qh - dmax .. qh cover the sample
+      if (dmax > qh) dmax = (int)qh;
+      T acc = T(0);
+      for (int dq = dmax; dq >= 0; --dq) {
+        const int64_t q = qh - dq;
+        if (q > a.nseg - 1) continue;
+        const int i = j + dq * hop;
+        int dd = i - roll;
+        if (dd < 0) dd += 2 * M;
+        const int e = dd >> 1, gs = (int)(q - m_lo);
+        acc += flat[2 * ((size_t)gs * TILE + (e & (R - 1)) * RS + (e >> LOG2R)) + (dd & 1)] * dual[i];
+      }
+      out[c * (a.k1 - a.k0) + (k - a.k0)] = acc * inv;
+    }
+  }
+}
+
 // Pxx[c][f] = w_f scale^2 / nseg * sum over the groups (index order) of their partial sums, w_f = 2 except at DC and Nyquist
 template <typename T>
 __global__ void k_welch_reduce(const double* __restrict__ part, T* __restrict__ pxx, int ngroups, int64_t nseg, int nf,
@@ -742,5 +872,69 @@ template int launch_welch_fused<float>(const float*, const float*, float*, doubl
                                        int64_t, double, hipStream_t);
 template int launch_welch_fused<double>(const double*, const double*, double*, double*, int64_t, int64_t, int64_t, int64_t,
                                         int64_t, int64_t, double, hipStream_t);
+
+// the fused inverse: supported for the fused kernel's transform lengths when a workgroup's LDS holds at least one owned hop
+// beside the halo slices
+template <typename T, int LR, int LC>
+static int launch_istft_shape(const cplx<T>* S, const T* dual, T* out, int64_t C, IstftArgs a, hipStream_t st) {
+  const int64_t M = 1ll << (LR + LC);
+  const size_t tile = ((size_t)1 << LR) * (((size_t)1 << LC) + 1) + 1, budget = 80 * 1024;
+  int G = (int)((budget / sizeof(cplx<T>) - (size_t)(M + 1)) / tile);
+  if (G > 16) G = 16;
+  if (G - a.halo < 1) return QI_ERR_UNSUPPORTED;
+  a.gown = G - a.halo;
+  // owned hops: every sample up to the end of the last slice
+  const int64_t hops = a.nseg + (a.seg - 1) / a.hop;
+  if (hops < a.gown) a.gown = (int32_t)hops;
+  a.ngroups = (int32_t)ceil_div(hops, a.gown);
+  a.log2gp = 0;
+  while ((1 << a.log2gp) < a.gown + a.halo) ++a.log2gp;
+  const size_t lds = ((size_t)(a.gown + a.halo) * tile + M + 1) * sizeof(cplx<T>);
+  const cplx<T>* twg = nullptr;
+  QI_TRY(stft_twiddles<T>(M, &twg));
+  QI_TRY(allow_dynamic_lds(reinterpret_cast<const void*>(&k_istft_fused<T, LR, LC>), lds));
+  if (a.k0 < a.first || a.k1 > a.first + hops * a.hop)  // (samples outside the hops the workgroups own)
+    QI_HIP(hipMemsetAsync(out, 0, (size_t)C * (size_t)(a.k1 - a.k0) * sizeof(T), st));
+  a.nitems = (int64_t)a.ngroups * C;
+  a.per_xcd = (int32_t)ceil_div(a.nitems, 8);
+  k_istft_fused<T, LR, LC><<<dim3((unsigned)(8 * a.per_xcd)), kStftThreads, lds, st>>>(S, dual, twg, out, a);
+  QI_LAUNCH_CHECK();
+  return QI_OK;
+}
+
+template <typename T>
+int launch_istft_fused(const cplx<T>* S, const T* dual, T* out, int64_t C, int64_t seg, int64_t hop, int64_t nfft, int64_t first,
+                       int64_t nseg, int64_t roll, int64_t k0, int64_t k1, hipStream_t st) {
+  int lr, lc;
+  if (!(nfft >= 64 && nfft <= 4096 && (nfft & (nfft - 1)) == 0 && seg <= nfft && seg >= 2 && hop >= 1 && hop <= seg) ||
+      !stft_shape<T>(nfft / 2, &lr, &lc))
+    return QI_ERR_UNSUPPORTED;
+  IstftArgs a{};
+  a.seg = seg;
+  a.hop = hop;
+  a.nseg = nseg;
+  a.first = first;
+  a.roll = roll;
+  a.k0 = k0;
+  a.k1 = k1;
+  a.halo = (int32_t)(ceil_div(seg, hop) - 1);
+  switch (lr * 8 + lc) {
+    case 2 * 8 + 3: return launch_istft_shape<T, 2, 3>(S, dual, out, C, a, st);
+    case 3 * 8 + 3: return launch_istft_shape<T, 3, 3>(S, dual, out, C, a, st);
+    case 3 * 8 + 4: return launch_istft_shape<T, 3, 4>(S, dual, out, C, a, st);
+    case 4 * 8 + 4: return launch_istft_shape<T, 4, 4>(S, dual, out, C, a, st);
+    case 4 * 8 + 5: return launch_istft_shape<T, 4, 5>(S, dual, out, C, a, st);
+    case 5 * 8 + 5: return launch_istft_shape<T, 5, 5>(S, dual, out, C, a, st);
+    case 5 * 8 + 6:
+      if constexpr (sizeof(T) == 4) return launch_istft_shape<T, 5, 6>(S, dual, out, C, a, st);
+      break;
+    default: break;
+  }
+  return QI_ERR_UNSUPPORTED;
+}
+template int launch_istft_fused<float>(const float2*, const float*, float*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
+                                       int64_t, int64_t, int64_t, hipStream_t);
+template int launch_istft_fused<double>(const double2*, const double*, double*, int64_t, int64_t, int64_t, int64_t, int64_t,
+                                        int64_t, int64_t, int64_t, int64_t, hipStream_t);
 
 }  // namespace qi
