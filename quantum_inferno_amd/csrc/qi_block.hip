@@ -451,7 +451,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       unit_root_t<T>(m, a.two_over_n, &c, &s);
       ph = mk<T>((T)c, (T)s);
     }
-    if constexpr (DEMOD && F64) {
+    if constexpr (DEMOD && F64 && COEF) {  // (reductions only: the demodulation, of modulus 1, changes no power)
       // float64: exp(-2 pi i idx t / n) of output i (t = V blk + col + 256 i) as a product of three exact-phase factors from
       // tables -- no double-precision sincospi per band and thread, and no phasor state carried through the epilogue (seed,
       // running power and two steps were 16 registers that did not fit beside the block spectrum: 270-390 bytes of scratch
@@ -490,7 +490,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
         for (int h = 0; h < 2; ++h) {
           z[h] = v[brev(i + h + WQ, 4)];
           if constexpr (DEMOD && F64) {
-            if (!QI_BDBG(32)) z[h] = cmul_rn(z[h], cmul_rn(ph, mk<T>(demod_pow[2 * (i + h)], demod_pow[2 * (i + h) + 1])));
+            if constexpr (COEF)
+              if (!QI_BDBG(32)) z[h] = cmul_rn(z[h], cmul_rn(ph, mk<T>(demod_pow[2 * (i + h)], demod_pow[2 * (i + h) + 1])));
           } else if (DEMOD && !QI_BDBG(32)) {
             if (i + h > 0) {
               if (((i + h) & 3) == 0) {

@@ -110,8 +110,16 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
     for (int i = tid; i < nwin; i += kZ64Threads) win[i] = C[(m_first + (uint32_t)i) & mmask];
     // carrier: exp(2 pi i k_c tau / Lf) at this thread's first sample, advanced by exp(2 pi i k_c 256 / Lf); the
     // phases are exact integers modulo Lf
+    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
+    // split band (bd.add_row): this is only the tapered part of its atom -- the samples go to row add_row - 1 of
+    // split_part and count for nothing here; the edge items of the block launch add their part and finish the band
+    const bool part = bd.add_row != 0;
+    cd* __restrict__ coef_row =
+        part ? a.split_part + ((int64_t)ch * a.split_rows + (bd.add_row - 1)) * n : (a.coef ? a.coef + orow : nullptr);
+    // (no sample leaves the kernel -- reductions only --: the carrier, of modulus 1, changes no power; the envelope will do)
+    const bool carrier = KIND != 2 && coef_row != nullptr;
     cd ph = mk<double>(1.0, 0.0), st = ph;
-    if (KIND != 2) {
+    if (carrier) {
       const uint32_t kc = (uint32_t)(bd.k_lo + bd.k_len / 2);
       double c, s;
       unit_root_t<double>((kc * (tau_first - (KIND == 0 ? 1u : 0u))) & lmask, a.two_over_len, &c, &s);
@@ -119,12 +127,6 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       unit_root_t<double>((kc * (uint32_t)kZ64Threads) & lmask, a.two_over_len, &c, &s);
       st = mk<double>(c, s);
     }
-    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
-    // split band (bd.add_row): this is only the tapered part of its atom -- the samples go to row add_row - 1 of
-    // split_part and count for nothing here; the edge items of the block launch add their part and finish the band
-    const bool part = bd.add_row != 0;
-    cd* __restrict__ coef_row =
-        part ? a.split_part + ((int64_t)ch * a.split_rows + (bd.add_row - 1)) * n : (a.coef ? a.coef + orow : nullptr);
     double* __restrict__ bits_row = a.bits && !part ? a.bits + orow : nullptr;
     const double pscale = part ? 0.0 : a.power_scale;
     double rowacc = 0.0, pl = 0.0;
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
         zi[j & 1] = fma(w[j], x.y, zi[j & 1]);
       }
       cd z = mk<double>(zr[0] + zr[1], zi[0] + zi[1]);
-      if (KIND != 2) {
+      if (carrier) {
         z = cmul_rn(z, ph);
         ph = cmul_rn(ph, st);
       }
@@ -271,8 +273,10 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
       smp_next = Cn[lane < NEED ? lane : NEED - 1];
       if (TWO) smq_next = Cn[kWave + (lane < NEED - kWave ? lane : NEED - kWave - 1)];
     }
+    // (reductions only, no split band: the carrier, of modulus 1, changes no power -- the envelope will do)
+    const bool carrier = KIND != 2 && (COEF || add_row != 0);
     cd ph = mk<double>(1.0, 0.0), st = ph;
-    if (KIND != 2) {
+    if (carrier) {
       // carrier exp(2 pi i k_c (tau - e) / Lf), tau = tau_wave + 64 s + lane: the wave's factor (tau_wave is a multiple of
       // kZ64FineWave: exact phase, table) x the lane's (table) at step 0, advanced by the exact step of 64 samples
       const uint32_t kc = (uint32_t)(bd->k_lo + bd->k_len / 2);
@@ -318,7 +322,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
 #pragma unroll
       for (int s = 0; s < GS; ++s) {
         cd z = mk<double>(zr[s], zi[s]);
-        if (KIND != 2 && !QI_ZDBG(16)) {
+        if (carrier && !QI_ZDBG(16)) {
           z = cmul_rn(z, ph);
           ph = cmul_rn(ph, st);
           zr[s] = z.x;

@@ -631,8 +631,10 @@ def test_float64_native_engine_vs_oracle(golden, order):
         assert torch.allclose(a.power_band, b.power_band, rtol=1e-9, atol=1e-12 * float(b.power_band.max()))
         assert torch.allclose(a.power_time, b.power_time, rtol=1e-8, atol=1e-11 * float(b.power_time.max()))
         assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-9)
+        # (reductions only: the float64 kernels leave out the unit-modulus carrier / demodulation factor of every output --
+        # the powers are those of the envelope, equal to a rounding)
         lean = getattr(nat, name)(xt[:, :], coef=False, reductions=True)
-        assert torch.equal(lean.reduced, a.reduced)
+        assert torch.allclose(lean.reduced, a.reduced, rtol=1e-12, atol=1e-14 * float(a.reduced.abs().max()))
         del a, b, lean
     if order == 3:
         # the float64 record against the REFERENCE run on the same float64 record (every band of both panels, all
@@ -684,7 +686,8 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
         zoom bands of several grids, block bands of both k_block64 variants (styx / Stockwell demodulation);
       * at 1 kHz record 0 against the REFERENCE run on the same float64 record, every band of both panels and every
         reduction (large_n1048576_o12_f64.npz; the reference is complex128 throughout: styx_stx.py:228, styx_cwt.py:195-198);
-      * the reductions of `coef=False` equal those of the stored-panel call bit for bit, and the per-band powers equal a direct
+      * the reductions of `coef=False` equal those of the stored-panel call to 1e-12 (the streaming kernels skip the unit-modulus
+        carrier / demodulation factor), and the per-band powers equal a direct
         sum over the stored panel (tfr_info.py:82-94)."""
     n, order = 1 << 20, 12
     tol = TOL[np.float64]
@@ -704,8 +707,11 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
     full = plan.cwt_stx(x, coef=True, reductions=True)
     lean = plan.cwt_stx(x, coef=False, reductions=True)
     torch.cuda.synchronize()
-    for a, b in zip(full, lean):
-        assert b.coef is None and torch.equal(a.reduced, b.reduced)
+    for a, b in zip(full, lean):  # (no carrier / demodulation factor when nothing is stored: equal to a rounding)
+        assert b.coef is None
+        assert torch.allclose(a.power_band, b.power_band, rtol=1e-12, atol=0.0)
+        assert torch.allclose(a.power_time, b.power_time, rtol=1e-12, atol=1e-14 * float(a.power_time.max()))
+        assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-12)
     # every record against its single-record run
     for c in range(channels):
         one = plan.cwt_stx(x[c : c + 1], coef=True, reductions=True)
