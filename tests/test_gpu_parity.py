@@ -1292,3 +1292,36 @@ def test_short_time_fft_wrappers_vs_reference(golden, dtype):
     # a batch of records through the same kernels
     two = stf.stft_tukey(np.stack([sig, sig[::-1]]), 800.0, 0.25, 256, 128)[2]
     assert np.array_equal(two[0], stf.stft_tukey(sig, 800.0, 0.25, 256, 128)[2])
+
+@pytest.mark.parametrize("dtype,seg,ov,log2n", [(np.float32, 2048, 1024, 17), (np.float32, 1024, 768, 16), (np.float32, 4096, 2048, 17),
+                                                (np.float64, 2048, 1024, 16), (np.float64, 512, 384, 15), (np.float32, 300, 150, 15)])
+def test_sliding_stft_istft_round_trip(dtype, seg, ov, log2n):
+    """ShortTimeFFT's convention, forward then inverse (qi_sliding_stft with the complex output, istft_tukey): with the
+    canonical dual window the record comes back, at shapes of the benchmark's size -- the fused inverse kernel's halo of 1
+    and 3 slices, both precisions, 4096-point transforms, and a transform length that is not a power of two (the
+    three-kernel path) for comparison."""
+    from quantum_inferno_amd import _lib
+    from quantum_inferno_amd.utilities import short_time_fft as stf
+
+    lib = _lib.require_gpu()
+    n, fs = 1 << log2n, 1000.0
+    rng = np.random.default_rng(seg + ov)
+    x = (orc.synth_chirp(n, fs, 0, 1, np.float64) + 0.3 * rng.standard_normal(n)).astype(dtype)
+    obj = stf.get_stft_object_tukey(fs, 0.25, seg, ov, "magnitude")
+    xt = torch.from_numpy(np.stack([x, x[::-1].copy()])).cuda()
+    p0, p1 = obj.p_min, obj.p_max(n)
+    n_slices, first = p1 - p0, p0 * obj.hop - obj.m_num_mid
+    cdt = torch.complex64 if dtype == np.float32 else torch.complex128
+    code = _lib.QI_F32 if dtype == np.float32 else _lib.QI_F64
+    win = torch.from_numpy(obj.win).to(device="cuda", dtype=xt.dtype)
+    z = torch.empty((2, obj.f_pts, n_slices), dtype=cdt, device="cuda")
+    nbytes = int(lib.qi_sliding_scratch_bytes(code, 2, obj.mfft, n_slices))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.qi_sliding_stft(code, 0, _lib.ptr(xt), 2, n, _lib.ptr(win), obj.m_num, obj.hop, obj.mfft, first, n_slices, 0, 0,
+                                   obj.m_num_mid, _lib.ptr(z), None, 1, _lib.ptr(scratch), nbytes, _lib.stream_ptr(xt.device)))
+    ts, back = stf.istft_tukey(z, fs, 0.25, seg, ov, "magnitude")
+    k1 = back.shape[1]
+    assert k1 == (n_slices - 1) * obj.hop and k1 >= n - seg
+    m = min(k1, n)
+    err = float((back[:, :m] - xt[:, :m]).abs().max()) / float(xt.abs().max())
+    assert err <= (2e-5 if dtype == np.float32 else 1e-12), (seg, ov, err)
