@@ -192,6 +192,31 @@ def test_bench_default_multirank_run_is_configs3_world2():
     assert "scaling_note" in line
 
 
+def test_bench_default_multirank_run_world8():
+    """The driver's N = 8 command line as it is (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`), with stub
+    transforms and short records on eight gloo ranks: configs[3] = 512 channels, eight rows in every gathered buffer, every
+    rank's seconds, waits and stage times in the line, value = the whole job's points over the slowest rank's time."""
+    import json
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+           "--stub", "1", "--log2n", "10", "--settle-ms", "0"]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["world_size"] == 8 and line["scaling"] == "weak"
+    assert cfg["channels_per_gpu"] == 64 and "512 channels" in cfg["workload"] and "configs[3]" in cfg["workload"]
+    assert cfg["points_per_step"] == 2 * 512 * cfg["bands"] * 1024
+    assert len(cfg["rank_seconds"]) == 8 and len(cfg["gather_wait_ms_per_step"]) == 8
+    assert all(len(v) == 8 for v in cfg["rank_stage_ms_per_step"].values())
+    assert abs(line["ms_per_step"] - max(cfg["rank_seconds"]) / 3 * 1e3) < 1e-3
+    assert abs(line["value"] - cfg["points_per_step"] / (line["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * line["value"]
+    assert line["configs1_per_gpu"]["n_gpus"] == 8
+
+
 def test_bench_stream_items_sharded_world2(tmp_path):
     """`bench.py --config 4 --stub 1` on two gloo ranks: the (channel block, chunk) items of the record set are dealt by
     stream.rank_items -- every item exactly once, a rank touches only records it owns (OwnedRecords raises otherwise),
