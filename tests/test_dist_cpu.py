@@ -213,7 +213,7 @@ def test_bench_default_multirank_run_world8():
     assert len(cfg["rank_seconds"]) == 8 and len(cfg["gather_wait_ms_per_step"]) == 8
     assert all(len(v) == 8 for v in cfg["rank_stage_ms_per_step"].values())
     assert abs(line["ms_per_step"] - max(cfg["rank_seconds"]) / 3 * 1e3) < 1e-3
-    assert abs(line["value"] - cfg["points_per_step"] / (line["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * line["value"]
+    assert abs(line["value"] - cfg["points_per_step"] / (line["ms_per_step"] * 1e-3) / 1e6) <= 1e-4 * line["value"]  # (rounded figures)
     assert line["configs1_per_gpu"]["n_gpus"] == 8
 
 
