@@ -608,6 +608,14 @@ def run_leg(a, ctx, cpu, extras=True):
             alg_launch = alg_step / launches_per_step
             achieved = alg_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
             traffic = tdata.get(f"{name}:{a.dtype}:n{a.log2n}:o{order:g}:c{n_ch}")
+            # the other ceiling of these kernels: vector wave instructions per launch (SQ_INSTS_VALU of the builder's counter
+            # pass, like `traffic`) x 4 cycles per wave64 instruction over the SIMD-cycles of the measured launch
+            valu = tdata.get(f"valu:{name}:{a.dtype}:n{a.log2n}:o{order:g}:c{n_ch}")
+            valu_issue = None
+            if valu is not None and per_launch_ms > 0:
+                valu_issue = {"wave_insts_per_launch": int(valu), "cycles_per_inst": 4, "simds": 1024, "clock_ghz": 2.4,
+                              "frac": round(valu * 4 / (1024 * per_launch_ms * 1e-3 * 2.4e9), 4),
+                              "source": tdata.get("source_valu")}
             return {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -616,6 +624,7 @@ def run_leg(a, ctx, cpu, extras=True):
                 "launch_ms": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
                 "algorithmic_bytes_per_launch": int(alg_launch), "bands_per_step": nb_stage,
                 "timed_in": "timed region (HIP events)" if timed else "3 untimed steps after the warmup (HIP events)",
+                "valu_issue": valu_issue,
             }
 
         dev_ms = sum(v[0] for v in stage_all.values()) / 3

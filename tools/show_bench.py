@@ -9,11 +9,13 @@ def show(x, ind=0):
     r = x["roofline"]
     print(f"{pad}{x['config']['workload'][:60]}")
     print(f"{pad}  value {x['value']:.0f}  ms/step {x['ms_per_step']}  step_frac {x['step_roofline'].get('frac')}")
-    print(f"{pad}  dominant {r['kernel']} frac {r['frac']} launch_ms {r.get('launch_ms')}")
+    vi = r.get("valu_issue")
+    print(f"{pad}  dominant {r['kernel']} frac {r['frac']} launch_ms {r.get('launch_ms')}" + (f" valu_issue {vi['frac']}" if vi else ""))
     if "stage_ms_per_step" not in x["step_roofline"]:
         return
     for k, v in x.get("stage_rooflines", {}).items():
-        print(f"{pad}  stage {k} frac {v['frac']} launch_ms {v['launch_ms']} x{v['launches_per_step']}")
+        vi = v.get("valu_issue")
+        print(f"{pad}  stage {k} frac {v['frac']} launch_ms {v['launch_ms']} x{v['launches_per_step']}" + (f" valu_issue {vi['frac']}" if vi else ""))
     print(f"{pad}  stages {x['step_roofline']['stage_ms_per_step']}")
     if "stft" in x:
         print(f"{pad}  stft {x['stft']['ms_per_step']} ms frac {x['stft']['frac']}")
