@@ -588,15 +588,15 @@ __global__ void __launch_bounds__(kStftThreads) k_istft_fused(const cplx<T>* __r
   for (int k = tid; k <= M; k += kStftThreads) tw[k] = twg[k];
   // fold: thread = (bin pair (k, M - k), slice): consecutive threads read consecutive slices of a frequency row
   // (slices along the low bits of the thread index, padded to a power of two: no division by G)
-  const int lgp = a.log2gp, g = tid & ((1 << lgp) - 1);
-  const int64_t m = m_lo + g;
-  const bool live = g < G && m >= 0 && m < a.nseg;
+  const int lgp = a.log2gp, gs = tid & ((1 << lgp) - 1);  // this thread's slice of the workgroup
+  const int64_t m = m_lo + gs;
+  const bool live = gs < G && m >= 0 && m < a.nseg;
   const cplx<T>* __restrict__ Sa = S + c * nf * a.nseg + m;
   // (the loads of UN sweeps are issued before any of them is used: the loop is bound by their latency)
   constexpr int UN = sizeof(T) == 4 ? 8 : 4;
   const int kstep = kStftThreads >> lgp;
-  cplx<T>* __restrict__ dg = data + (size_t)g * TILE;
-  for (int kb0 = tid >> lgp; g < G && kb0 <= M / 2; kb0 += UN * kstep) {
+  cplx<T>* __restrict__ dg = data + (size_t)gs * TILE;
+  for (int kb0 = tid >> lgp; gs < G && kb0 <= M / 2; kb0 += UN * kstep) {
     cplx<T> xa[UN], xb[UN], wk[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
