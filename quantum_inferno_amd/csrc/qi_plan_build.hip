@@ -567,6 +567,15 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       for (size_t q = 0; q < list.size(); ++q) {
         const auto& b = list[q];
         for (int k = 0; k < native::kBlk; ++k) {
+          if (b.analytic == 2) {  // an atom shorter than 2.75 samples: every alias that matters, alternating in sign
+            double acc = 0.0;
+            for (int m = -6; m <= 6; ++m) {
+              const double e = (double)b.cw * ((double)(k - b.kappa_int) - (double)b.kappa_frac + (double)native::kBlk * m);
+              acc += ((m & 1) && !demod ? -1.0 : 1.0) * std::exp2(-e * e);
+            }
+            gw[q * native::kBlk + k] = (double)b.amp * acc;
+            continue;
+          }
           double dk = (double)(k - b.kappa_int) - (double)b.kappa_frac, amp = (double)b.amp;
           if (dk > (double)(native::kBlk / 2)) {
             dk -= (double)native::kBlk;
@@ -781,6 +790,15 @@ int build_native_bank(qi_plan* p, int bank, int32_t B, const double* d_par, cons
       // frequency inside (0, pi): its 4096-point filter spectrum is amp sqrt(pi / p) exp(-d^2 / 4p) exp(-i theta / 2)
       if (p_im == 0.0 && p_re > 0.0 && p_re <= 1.0 / (2.0 * 2.75 * 2.75) && om > 0.0 && om < M_PI) {
         pk.analytic = 1;
+        pk.kappa = om * (double)native::kBlk / (2.0 * M_PI);
+        pk.cw = (2.0 * M_PI / (double)native::kBlk) * std::sqrt(M_LOG2E / (4.0 * p_re));
+        pk.amp = am * std::sqrt(M_PI / p_re) / (double)native::kBlk;
+      }
+      // float64, an atom SHORTER than 2.75 samples (the top band of an order-1 or order-2 table): its sampled spectrum is the
+      // Gaussian plus its aliases, sum over m of (-1)^m G(theta + 2 pi m) after the half-sample factor -- still real weights,
+      // which the plan-time weight table holds summed (analytic = 2: table only; float32 reads such a band's bank row)
+      if (p->d.dtype == QI_F64 && !pk.analytic && p->native_blk64_wtab && p_im == 0.0 && p_re > 0.0 && om > 0.0 && om < M_PI) {
+        pk.analytic = 2;
         pk.kappa = om * (double)native::kBlk / (2.0 * M_PI);
         pk.cw = (2.0 * M_PI / (double)native::kBlk) * std::sqrt(M_LOG2E / (4.0 * p_re));
         pk.amp = am * std::sqrt(M_PI / p_re) / (double)native::kBlk;

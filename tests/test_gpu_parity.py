@@ -763,12 +763,15 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
 
 
 @pytest.mark.parametrize("log2n,name,order", [(19, "cwt", 6), (21, "stx", 6), (16, "cwt", 12), (16, "stx", 3), (18, "cwt", 3),
-                                              (18, "stx", 12), (22, "cwt", 6), (22, "stx", 6), (15, "cwt", 6)])
+                                              (18, "stx", 12), (22, "cwt", 6), (22, "stx", 6), (15, "cwt", 6),
+                                              (16, "cwt", 1), (18, "cwt", 2), (20, "cwt", 1)])
 def test_float64_native_engine_other_lengths(log2n, name, order):
     """The float64 engines (float64 zoom, block engine in double, split bands) at other record lengths than 2^20: every
     power of two from 2^15 to 2^22 whose band table leaves nothing for the two-pass kernels (round 3 ran these on the hipFFT
     engine, 13-25 x slower, except the two shapes with 2^20 / 2^21-point transforms).  Against the ORACLE on bands of every
-    engine at the float64 tolerance, and against the hipFFT engine: every row to its own maximum, and the fused reductions."""
+    engine at the float64 tolerance, and against the hipFFT engine: every row to its own maximum, and the fused reductions.
+    Orders 1 and 2 (round 4): their top band's atom is shorter than 2.75 samples -- the block engine in double takes it with the
+    aliases of its Gaussian spectrum summed in the weight table."""
     from quantum_inferno_amd import _lib
 
     n, fs = 1 << log2n, 1000.0
