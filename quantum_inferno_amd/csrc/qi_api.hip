@@ -432,9 +432,14 @@ int qi_stx(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, qi_str
   QI_REQUIRE(C > 0, "n_channels must be positive");
   DeviceGuard g(p->d.device);
   p->prof.unchain();
-  if (p->nat[2].ready)
-    return p->d.dtype == QI_F64 ? run_native64(p, 2, sig, C, out, (hipStream_t)stream)
-                                : run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
+  if (p->nat[2].ready) {
+    int rc = p->d.dtype == QI_F64 ? run_native64(p, 2, sig, C, out, (hipStream_t)stream)
+                                  : run_native<float>(p, 2, sig, C, out, (hipStream_t)stream);
+    if (rc == QI_OK && p->stx_left_n > 0)  // the rows no native engine takes at this length: the hipFFT engine's pass over them
+      rc = p->d.dtype == QI_F64 ? run_stx_leftover<double>(p, sig, C, out, (hipStream_t)stream)
+                                : run_stx_leftover<float>(p, sig, C, out, (hipStream_t)stream);
+    return rc;
+  }
   return p->d.dtype == QI_F64 ? run_transform<double>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream)
                               : run_transform<float>(p, Kind::Stockwell, sig, C, out, (hipStream_t)stream);
 }
@@ -455,7 +460,7 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
                qi_stream stream) {
   QI_REQUIRE(p && sig && out_cwt && out_stx, "null argument");
   QI_REQUIRE(bank == QI_BANK_STYX, "qi_cwt_stx runs the styx bank (bank %d given)", bank);
-  const bool fuse = p->native_fuse && p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready;
+  const bool fuse = p->native_fuse && p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready && p->stx_left_n == 0;
   p->carry.active = false;
   p->carry.has_zoom = false;
   QI_REQUIRE(C > 0, "n_channels must be positive");
@@ -597,7 +602,7 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
     }
   }
   QI_TRY(qi_cwt(p, bank, sig, C, out_cwt, stream));
-  if (p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready) {  // separate launches, but the Stockwell run may still use the CWT's spectra
+  if (p->d.dtype == QI_F32 && p->nat[bank].ready && p->nat[2].ready && p->stx_left_n == 0) {  // separate launches, but the Stockwell run may still use the CWT's spectra
     DeviceGuard g(p->d.device);
     p->prof.unchain();
     const int rc = run_native<float>(p, 2, sig, C, out_stx, st, /*may_share=*/true, nullptr, nullptr);

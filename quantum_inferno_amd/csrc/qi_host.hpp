@@ -357,6 +357,11 @@ struct qi_plan {
   double2* d_demod_t1 = nullptr;  // float64 block engine, Stockwell demodulation: exp(-2 pi i 1024 j / n), j < n / 1024
   double2* d_demod_t2 = nullptr;  // ... exp(-2 pi i j / n), j < 1024
   int native_z64_fine = 1;  // 0: every level on k_z64_interp (windows through LDS), as in round 3
+  // Stockwell bands that no native engine takes at this record length (the two-pass kernels run 2^20 / 2^21 samples only): when
+  // they are the last rows of the table -- the top band of an order-1 or order-2 table, whose frequency window is cut at the
+  // Nyquist bins -- the native run leaves them out and a pass of the hipFFT engine over just these rows follows it
+  // (run_stx_leftover); any other case hands the whole table to the hipFFT engine as before
+  int32_t stx_left_lo = -1, stx_left_n = 0;
   int native_blk64_wtab = 1;  // float64 block engine: Gaussian filter weights from a plan-time table instead of sixteen exp2 per band and thread
   int native_z64_block_from = 4;  // a band that needs coarse-grid level >= this (0-based) goes to the block engine when its atom is short enough
   int native_z64_coarse = 3;  // coarse-grid levels whose coarse stage is one launch of in-LDS plane transforms (the finer ones: hipFFT)
@@ -443,6 +448,8 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
 template <typename T>
 int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st,
                bool may_share = false, FusedCarry* defer = nullptr, FusedCarry* finish = nullptr, size_t* probe = nullptr);
+template <typename T>
+int run_stx_leftover(qi_plan* p, const void* sig, int64_t C, const qi_tfr_out* out, hipStream_t st);
 int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st);
 int flush_carry(qi_plan* p, FusedCarry* c, hipStream_t st);
 

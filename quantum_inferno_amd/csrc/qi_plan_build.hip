@@ -1,5 +1,7 @@
 // The tables of a plan: support analysis of the atom spectra, assignment of every band to an engine (zoom classes, block
 // reach groups, split bands, two-pass groups), the device tables and work-item lists of those engines.
+#include <algorithm>
+
 #include "qi_host.hpp"
 
 using namespace qi;
@@ -1016,6 +1018,23 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
         ngen++;
       }
     }
+    p->stx_left_lo = -1;
+    p->stx_left_n = 0;
+    if (!native_len_ok(p->n) && p->d.engine != QI_ENGINE_NATIVE) {
+      // bands for the two-pass kernels at a length they do not run: if they are the last (at most four) rows of the table, a
+      // pass of the hipFFT engine over those rows follows the native run (run_stx_leftover)
+      int32_t lo = B, cnt = 0;
+      for (const auto& d : bands)
+        if (d.mode == 1) {
+          ++cnt;
+          lo = d.out_band < lo ? d.out_band : lo;
+        }
+      if (cnt > 0 && cnt <= 4 && lo == B - cnt && cnt < B) {
+        bands.erase(std::remove_if(bands.begin(), bands.end(), [](const native::BandDesc& d) { return d.mode == 1; }), bands.end());
+        p->stx_left_lo = lo;
+        p->stx_left_n = cnt;
+      }
+    }
     bool two_pass_free = true;  // no band for pass 1 / pass 2 (their transform lengths are 2^20 and 2^21 only)
     for (const auto& d : bands) two_pass_free = two_pass_free && d.mode >= 2;
     // (float64: the float64 zoom takes its bands inside upload_native_table -- what it leaves is known afterwards)
@@ -1025,6 +1044,7 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
       if (rc == QI_OK && !native_len_ok(p->n) && !p->nat[2].h_rows.empty()) {
         p->nat[2].release();  // bands are left for the two-pass kernels at a length they do not run: the hipFFT engine takes the table
         p->blk[2].release();
+        p->stx_left_n = 0;
         if (p->d.engine == QI_ENGINE_NATIVE) {
           set_error("native engine: this Stockwell band table needs the two-pass kernels, which run 2^20 / 2^21 samples only");
           return QI_ERR_UNSUPPORTED;
@@ -1038,6 +1058,7 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
       if (rc != QI_OK) {  // no half-built table: a ready table whose block bands have no producer would leave panel rows unwritten
         p->nat[2].release();
         p->blk[2].release();
+        p->stx_left_n = 0;
         return rc;
       }
     } else if (p->d.engine == QI_ENGINE_NATIVE) {

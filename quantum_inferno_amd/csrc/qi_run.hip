@@ -137,6 +137,88 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
   return QI_OK;
 }
 
+// Stockwell rows [stx_left_lo, nb_stx) behind a native run that left them out (qi_plan::stx_left_*): the hipFFT engine's
+// window -> inverse transform -> epilogue over just these rows; the per-time sums are added to the native run's, the rows'
+// powers and the panel statistics merged by k_left_merge (fixed order).
+namespace {
+__global__ void __launch_bounds__(256) k_left_merge(const double* __restrict__ part_band, const double* __restrict__ part_stat,
+                                                    double* __restrict__ power_band, double* __restrict__ stats, int64_t B,
+                                                    int64_t j0, int64_t bt, int64_t nblk) {
+  const int64_t c = blockIdx.x;
+  if (threadIdx.x < bt && power_band) {
+    const double* q = part_band + (c * B + j0 + threadIdx.x) * nblk;
+    double s = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) s += q[b];
+    power_band[c * B + j0 + threadIdx.x] = s;
+  }
+  if (threadIdx.x == 64 && stats) {
+    const double* q = part_stat + ((c * 2 + 1) * nblk) * 3;  // (the epilogue ran as tile 1 of 2)
+    double m = stats[c * 4 + 0], s1 = 0.0, s2 = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) {
+      m = q[3 * b] > m ? q[3 * b] : m;
+      s1 += q[3 * b + 1];
+      s2 += q[3 * b + 2];
+    }
+    stats[c * 4 + 0] = m;
+    stats[c * 4 + 1] += s1;
+    stats[c * 4 + 2] += s2;
+  }
+}
+}  // namespace
+
+template <typename T>
+int run_stx_leftover(qi_plan* p, const void* sig_v, int64_t C, const qi_tfr_out* out, hipStream_t st) {
+  const int64_t n = p->n, B = p->nb_stx, j0 = p->stx_left_lo, bt = p->stx_left_n;
+  const T* sig = static_cast<const T*>(sig_v);
+  Tile tl;
+  QI_TRY(plan_tiles<T>(p, C, B, n, &tl));
+  if (tl.Bt < bt) {
+    set_error("workspace too small for the %lld Stockwell rows behind the native run", (long long)bt);
+    return QI_ERR_NOMEM;
+  }
+  cplx<T>* X = reinterpret_cast<cplx<T>*>(p->ws + tl.off_x);
+  cplx<T>* Y = reinterpret_cast<cplx<T>*>(p->ws + tl.off_y);
+  double* part_band = reinterpret_cast<double*>(p->ws + tl.off_pb);
+  double* part_stat = reinterpret_cast<double*>(p->ws + tl.off_ps);
+  const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
+  for (int64_t c0 = 0; c0 < C; c0 += tl.Ct) {
+    const int64_t ct = (C - c0 < tl.Ct) ? C - c0 : tl.Ct;
+    QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, n, st));
+    QI_TRY(fft_c2c<T>(p->fft, X, n, ct, HIPFFT_FORWARD, st));
+    QI_TRY(launch_stx_window<T>(X, Y, ct, bt, n, p->d_stx_idx + j0, p->d_stx_coef + j0, st));
+    QI_TRY(fft_c2c<T>(p->fft, Y, n, ct * bt, HIPFFT_BACKWARD, st));
+    EpiArgs<T> a{};
+    a.Y = Y;
+    a.L = n;
+    a.n = n;
+    a.off = 0;
+    a.Ct = ct;
+    a.Bt = bt;
+    a.B = B;
+    a.j0 = j0;
+    a.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
+    a.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
+    a.power_time = out->power_time ? static_cast<T*>(out->power_time) + c0 * n : nullptr;
+    a.part_band = want_band ? part_band : nullptr;
+    a.part_stat = want_stat ? part_stat : nullptr;
+    a.tile_b = 1;  // (not the first tile of the panel: the per-time sums are ADDED to what the native run wrote)
+    a.ntile_b = 2;
+    a.power_scale = (T)(out->power_scale == 0.0 ? 1.0 : out->power_scale);
+    a.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
+    QI_TRY(launch_epilogue<T>(a, st));
+    if (want_band || want_stat) {
+      k_left_merge<<<dim3((unsigned)ct), 256, 0, st>>>(part_band, part_stat,
+                                                     want_band ? static_cast<double*>(out->power_band) + c0 * B : nullptr,
+                                                     want_stat ? static_cast<double*>(out->stats) + c0 * 4 : nullptr, B, j0, bt,
+                                                     tl.nblk);
+      QI_HIP(hipGetLastError());
+    }
+  }
+  return QI_OK;
+}
+template int run_stx_leftover<float>(qi_plan*, const void*, int64_t, const qi_tfr_out*, hipStream_t);
+template int run_stx_leftover<double>(qi_plan*, const void*, int64_t, const qi_tfr_out*, hipStream_t);
+
 // One transform on the native engine: forward FFT of the records (hipFFT), then per table (the styx bank has two:
 // the 2n-point linear part and the n-point circular part for short atoms) pass 1 for the wide bands and pass 2 with
 // the fused epilogue for every band, the edge correction of the short-atom bands, and a fixed-order finalisation of

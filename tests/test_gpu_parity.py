@@ -1328,3 +1328,51 @@ def test_sliding_stft_istft_round_trip(dtype, seg, ov, log2n):
     m = min(k1, n)
     err = float((back[:, :m] - xt[:, :m]).abs().max()) / float(xt.abs().max())
     assert err <= (2e-5 if dtype == np.float32 else 1e-12), (seg, ov, err)
+
+@pytest.mark.parametrize("dtype,log2n,order", [(np.float32, 16, 1), (np.float32, 18, 2), (np.float64, 16, 1), (np.float64, 17, 2)])
+def test_stockwell_rows_behind_the_native_run(dtype, log2n, order):
+    """Order-1 / order-2 Stockwell tables at lengths other than 2^19 / 2^20: the top band's frequency window is cut at the
+    Nyquist bins, no native engine takes it there, and (round 4) the native run leaves that row to a pass of the hipFFT
+    engine over just it -- the whole table had gone to the hipFFT engine before.  Every row and every reduction against the
+    hipFFT engine, the last rows against the oracle, through stx, cwt_stx and the reductions-only call."""
+    from quantum_inferno_amd import _lib
+
+    n, fs = 1 << log2n, 1000.0
+    rng = np.random.default_rng(log2n + int(order))
+    x = np.stack([orc.synth_chirp(n, fs, c, 2, np.float64) for c in range(2)]) + 0.2 * rng.standard_normal((2, n))
+    x = x.astype(dtype)
+    xt = torch.from_numpy(x).cuda()
+    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
+    ws = engine.TfrPlan.workspace_for(n, nb, dtype, 2)
+    nat = engine.TfrPlan(n, dtype, None, ws, _lib.QI_ENGINE_AUTO)
+    ref = engine.TfrPlan(n, dtype, None, ws, _lib.QI_ENGINE_HIPFFT)
+    for plan in (nat, ref):
+        plan.set_styx_bank(order, fs)
+        plan.set_stx_bands(order, fs)
+    native_rows = nat.stage_bands("zoom")[2] + nat.stage_bands("block")[2]
+    assert 0 < native_rows < nb and nb - native_rows <= 4  # (the zoom and block engines ran all but the last rows)
+    a = nat.stx(xt, coef=True, bits=True, reductions=True)
+    b = ref.stx(xt, coef=True, bits=True, reductions=True)
+    f64 = dtype == np.float64
+    for row in range(nb):
+        scale = float(b.coef[:, row].abs().max())
+        assert float((a.coef[:, row] - b.coef[:, row]).abs().max()) <= (5e-9 if f64 else 2e-5) * scale, row
+    assert torch.allclose(a.power_band, b.power_band, rtol=1e-9 if f64 else 1e-4)
+    assert torch.allclose(a.power_time, b.power_time, rtol=1e-8 if f64 else 1e-3, atol=(1e-11 if f64 else 1e-6) * float(b.power_time.max()))
+    assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-9 if f64 else 1e-4)
+    big = b.coef.abs() >= 1e-2 * float(b.coef.abs().max())
+    assert float((a.bits - b.bits).abs()[big].max()) <= (1e-8 if f64 else 1e-3)
+    pick = [nb - 3, nb - 2, nb - 1]
+    _, _, want = orc.stx_fft(order, x[1].astype(np.float64), fs, bands=pick)
+    got = a.coef[1][torch.tensor(pick, device="cuda")].cpu().numpy()
+    for i, j in enumerate(pick):
+        assert np.max(np.abs(got[i] - want[i])) <= (5e-9 if f64 else 2e-5) * np.max(np.abs(want[i])), j
+    # the joint call and the reductions-only call take the same route
+    fc, fs_ = nat.cwt_stx(xt, coef=True, reductions=True)
+    assert float((fs_.coef - a.coef).abs().max()) <= (1e-12 if f64 else 2e-6) * float(a.coef.abs().max())
+    assert torch.allclose(fs_.power_band, a.power_band, rtol=1e-12 if f64 else 1e-5)
+    lean = nat.stx(xt, coef=False, reductions=True)
+    assert lean.coef is None and torch.allclose(lean.power_band, a.power_band, rtol=1e-12 if f64 else 1e-5)
+    assert torch.allclose(lean.stats[:, :3], a.stats[:, :3], rtol=1e-12 if f64 else 1e-5)
+    nat.close()
+    ref.close()
