@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--stub-ms", type=float, default=0.0,
                     help="with --stub: every stub transform call takes this long (a fixed step time, so that a rehearsed N-rank "
                          "line can be checked against N x the one-rank line)")
+    ap.add_argument("--force-collective", type=int, default=0,
+                    help="1: a ONE-rank run initialises the process group too (nccl = RCCL, world size 1) and every step ends in "
+                         "the real pipelined gather-to-self: the multi-rank code path on a one-GPU box")
     ap.add_argument("--stub-dump", default="", help="with --stub: rank 0 saves the last gathered buffers here (torch.save)")
     return ap.parse_args()
 
@@ -231,7 +234,7 @@ def stream_bench(args, ctx, cpu):
     for _ in range(warm):
         next(it)
     ctx.sync()
-    if world > 1:
+    if ctx.coll:
         dist.barrier()
     t0 = time.perf_counter()
     done, entropy, seen = 0, 0.0, []
@@ -240,13 +243,13 @@ def stream_bench(args, ctx, cpu):
         seen.append((item.first_channel, item.chunk))
         done += 1
     ctx.sync()
-    if world > 1:
+    if ctx.coll:
         dist.barrier()
     dt_local = time.perf_counter() - t0
     rank_dt = [dt_local]
     rank_items_done = [done]
     dt = dt_local
-    if world > 1:
+    if ctx.coll:
         t = torch.tensor([dt, float(done)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
@@ -280,7 +283,7 @@ def stream_bench(args, ctx, cpu):
                             f"samples with a hop of 2^{args.log2n - 1} @ {fs:g} Hz, order N={order:g}, CWT+STX+entropy ({n_b} bands), "
                             f"reduced products only; {n_ch} records x {items} chunks per GPU here, 128 x 131 in the 24 h job",
                 "channels_per_gpu": n_ch, "n": n, "bands": n_b, "points_per_step": points_item * world,
-                "world_size": dist.get_world_size() if world > 1 else 1, "backend": ctx.backend,
+                "world_size": dist.get_world_size() if ctx.coll else 1, "backend": ctx.backend,
                 "rank_seconds": [round(v, 6) for v in rank_dt], "rank_items": rank_items_done,
                 "h2d_ms_per_item": h2d_ms,
                 "projected_seconds_24h_1024ch_8gpu": round(full_items * dt / max(done, 1), 1),
@@ -376,8 +379,10 @@ class StubPlan:
 class Ctx:
     """What every leg of one bench run shares: the rank layout, the device and the process group."""
 
-    def __init__(self, world, rank, local, dev, stub, backend):
+    def __init__(self, world, rank, local, dev, stub, backend, coll=None):
         self.world, self.rank, self.local, self.dev, self.stub, self.backend = world, rank, local, dev, stub, backend
+        # coll: a process group exists and every step ends in the gather (N > 1 ranks, or --force-collective on one)
+        self.coll = (world > 1) if coll is None else coll
 
     def sync(self):
         if not self.stub:
@@ -423,7 +428,7 @@ def fit_workspace(a, ctx, n, n_b, tdtype, real_bytes, depth):
     free, total = torch.cuda.mem_get_info(ctx.dev)
     msg = 2 * qdist.reduced_slots(n_ch, n_b, n, tdtype) * 8
     panels = 2 * n_ch * n_b * n * 2 * real_bytes
-    recv = depth * ctx.world * msg if (ctx.world > 1 and ctx.rank == 0) else 0
+    recv = depth * ctx.world * msg if (ctx.coll and ctx.rank == 0) else 0
     stft = 0
     if a.stft:
         seg = 2048 if a.order >= 12 else 512  # (an upper bound is enough here)
@@ -462,7 +467,7 @@ def run_leg(a, ctx, cpu, extras=True):
     bands = qi.scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order)
     n_b = len(bands)
     engine_code = {"auto": _lib.QI_ENGINE_AUTO, "hipfft": _lib.QI_ENGINE_HIPFFT, "native": _lib.QI_ENGINE_NATIVE}[a.engine]
-    depth = 2 if world > 1 else 1
+    depth = 2 if ctx.coll else 1
     ws, budget = fit_workspace(a, ctx, n, n_b, tdtype, real_bytes, depth)
     if stub:
         plan = StubPlan(n, n_b, rank, step_ms=a.stub_ms)
@@ -486,7 +491,7 @@ def run_leg(a, ctx, cpu, extras=True):
         oc.coef, os_.coef = outs[0][0].coef, outs[0][1].coef  # (None in a --stub run)
         outs.append((oc, os_))
     small = n_ch * order <= 12  # a step of a quarter of a millisecond: every recorded event shows
-    pipe = qdist.GatherPipeline(depth=depth, dst=0, timing=world > 1 and not small)
+    pipe = qdist.GatherPipeline(depth=depth, dst=0, timing=ctx.coll and not small, force_collective=ctx.coll)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if not stub else None
     stft_ms = []
 
@@ -497,7 +502,7 @@ def run_leg(a, ctx, cpu, extras=True):
             stft.run(sig)
             if time_stft:
                 ev[1].record()
-        if world == 1:
+        if not ctx.coll:
             plan.cwt_stx(sig, out=outs[0])  # qi_cwt_stx: both transforms of the same records in one call
             msg = qdist.pack_reduced(list(outs[0]))
         else:
@@ -514,7 +519,7 @@ def run_leg(a, ctx, cpu, extras=True):
     def fence():
         last_gathered[:] = pipe.drain()
         device_sync()
-        if world > 1:
+        if ctx.coll:
             dist.barrier()
         device_sync()
 
@@ -526,7 +531,7 @@ def run_leg(a, ctx, cpu, extras=True):
     while True:
         device_sync()
         done = (time.perf_counter() - t_warm) * 1e3 >= a.settle_ms
-        if world > 1:  # every rank runs the same number of steps (each step ends in a collective)
+        if ctx.coll:  # every rank runs the same number of steps (each step ends in a collective)
             flag = torch.tensor([1.0 if done else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             done = bool(flag.item() > 0.5)
@@ -575,7 +580,7 @@ def run_leg(a, ctx, cpu, extras=True):
     # share its CUs with the transforms -- then shows as longer kernels THERE, apart from the time spent waiting for a gather
     stage_names = sorted(k for k, v in stage_all.items() if v[1])
     rank_stage_ms = {k: [round(stage_all[k][0] / 3, 4)] for k in stage_names}
-    if world > 1:
+    if ctx.coll:
         n_ranks = dist.get_world_size()
         from quantum_inferno_amd._lib import STAGES as all_stages
 
@@ -674,8 +679,8 @@ def run_leg(a, ctx, cpu, extras=True):
                 "backend": ctx.backend,
                 "rank_seconds": [round(v, 6) for v in rank_dt],
                 "gather_wait_ms_per_step": [round(v, 4) for v in wait_ms] if pipe.timing else None,
-                "gather_message_bytes_per_rank": int(2 * slots * 8) if world > 1 else 0,
-                "rank_stage_ms_per_step": rank_stage_ms if world > 1 else None,
+                "gather_message_bytes_per_rank": int(2 * slots * 8) if ctx.coll else 0,
+                "rank_stage_ms_per_step": rank_stage_ms if ctx.coll else None,
             },
             "roofline": stage_roofline(dominant),
             "step_roofline": {
@@ -765,7 +770,7 @@ def run_leg(a, ctx, cpu, extras=True):
         if stub:
             line["data"] = "stub (CPU rehearsal of the rank plumbing, no transform ran)"
             if a.stub_dump:
-                gathered = [g.clone() if g is not None else None for g in last_gathered] if world > 1 else [qdist.pack_reduced(list(outs[0])).unsqueeze(0)]
+                gathered = [g.clone() if g is not None else None for g in last_gathered] if ctx.coll else [qdist.pack_reduced(list(outs[0])).unsqueeze(0)]
                 torch.save({"gathered": gathered, "slots": slots, "n_ch": n_ch, "n_b": n_b, "n": n, "calls": plan.calls}, a.stub_dump)
     plan.close()
     # hand every buffer of this leg back before the next one sizes itself (configs[2] holds 2 x 89.7 GB of panels)
@@ -818,8 +823,15 @@ def main():
 
     stub = bool(args.stub)
     backend = "none"
-    if world > 1:
+    coll = world > 1 or bool(args.force_collective)
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (a forced one-rank group outside torch.distributed.run)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if stub:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -831,7 +843,7 @@ def main():
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    ctx = Ctx(world, rank, local, dev, stub, backend)
+    ctx = Ctx(world, rank, local, dev, stub, backend, coll)
 
     line = None
     for (key, a, _), cpu in zip(legs, cpus):
@@ -860,7 +872,7 @@ def main():
                                         "channels_per_gpu": base["config"]["channels_per_gpu"],
                                         "points_per_step": base["config"]["points_per_step"]}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

@@ -67,12 +67,14 @@ def unpack_reduced(flat, n_channels, shapes, time_dtype=torch.float32):
 _GATHER_BUFFERS = {}
 
 
-def gather_reduced(flat, dst=0, group=None, async_op=False, slot=0):
+def gather_reduced(flat, dst=0, group=None, async_op=False, slot=0, force_collective=False):
     """Gather equal-sized reduced buffers to `dst`; returns [world, len] there, None elsewhere.  The receive buffer is
     kept between calls (one [world, len] allocation per shape and `slot`), the ranks' messages land in its rows directly.
     async_op: returns (buffer or None, work) without waiting -- `work.wait()` before `flat` is written again or the
-    buffer is read (see GatherPipeline)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    buffer is read (see GatherPipeline).  A group of ONE rank returns the message itself, without a collective, unless
+    `force_collective` asks for the real gather-to-self (how the RCCL branch is exercised on a one-GPU box)."""
+    ready = dist.is_available() and dist.is_initialized()
+    if not ready or (dist.get_world_size(group) == 1 and not force_collective):
         return (flat.unsqueeze(0), None) if async_op else flat.unsqueeze(0)
     world = dist.get_world_size(group)
     out, rows = None, None
@@ -110,8 +112,8 @@ class GatherPipeline:
         gathered = pipe.drain()           # list of the receive buffers on `dst` (None elsewhere)
     """
 
-    def __init__(self, depth=2, dst=0, group=None, timing=False):
-        self.depth, self.dst, self.group = depth, dst, group
+    def __init__(self, depth=2, dst=0, group=None, timing=False, force_collective=False):
+        self.depth, self.dst, self.group, self.force_collective = depth, dst, group, force_collective
         self.works = [None] * depth
         self.outs = [None] * depth
         self.k = 0
@@ -152,7 +154,8 @@ class GatherPipeline:
         return self._host_wait * 1e3 + sum(a.elapsed_time(b) for a, b in self._pairs)
 
     def submit(self, i, flat):
-        self.outs[i], self.works[i] = gather_reduced(flat, self.dst, self.group, async_op=True, slot=i)
+        self.outs[i], self.works[i] = gather_reduced(flat, self.dst, self.group, async_op=True, slot=i,
+                                                          force_collective=self.force_collective)
         self.k += 1
         return self.outs[i]
 

@@ -270,3 +270,44 @@ def test_bench_scaling_base_consistent_with_multirank_value_world2():
     assert abs(two["value"] - two["config"]["points_per_step"] * two["steps"] / max(two["config"]["rank_seconds"]) / 1e6) <= 1e-3 * two["value"]
     stages = two["config"]["rank_stage_ms_per_step"]
     assert stages and all(len(v) == 2 for v in stages.values()) and "block" in stages and "zoom" in stages
+
+
+def test_forced_collective_on_one_rank_gloo():
+    """`force_collective` takes a ONE-rank group through the real gather (what tests/test_gpu_rccl.py does with RCCL on the
+    GPU box), here with gloo: GatherPipeline with buffer reuse, and bench.py's N-rank branch under --force-collective 1."""
+    import json
+    import subprocess
+
+    code = (
+        "import torch, torch.distributed as dist\n"
+        "from quantum_inferno_amd import dist as qdist\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "base = torch.arange(64, dtype=torch.float64)\n"
+        "msgs = [torch.empty(64, dtype=torch.float64) for _ in range(2)]\n"
+        "pipe = qdist.GatherPipeline(depth=2, timing=True, force_collective=True)\n"
+        "seen = []\n"
+        "for k in range(7):\n"
+        "    i = pipe.acquire()\n"
+        "    if pipe.outs[i] is not None: seen.append((k - 2, pipe.outs[i].clone()))\n"
+        "    msgs[i].copy_(base + 10.0 * k)\n"
+        "    out = pipe.submit(i, msgs[i])\n"
+        "    assert out.data_ptr() != msgs[i].data_ptr()\n"
+        "outs = pipe.drain()\n"
+        "assert all(torch.equal(b[0], base + 10.0 * k) for k, b in seen) and len(seen) == 5\n"
+        "assert torch.equal(outs[0][0], base + 60.0) and torch.equal(outs[1][0], base + 50.0)\n"
+        "assert qdist.gather_reduced(base)[0].data_ptr() == base.data_ptr()  # unforced: the message itself\n"
+        "dist.destroy_process_group()\n"
+    )
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), PYTHONPATH=ROOT)
+    run = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-3000:]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--channels", "3", "--log2n", "12", "--stub", "1",
+           "--force-collective", "1", "--steps", "5", "--warmup", "2", "--cpu-seconds", "0"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["config"]["backend"] == "gloo" and line["config"]["world_size"] == 1
+    assert line["config"]["gather_message_bytes_per_rank"] > 0 and line["config"]["gather_wait_ms_per_step"] is not None

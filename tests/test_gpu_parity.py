@@ -3,7 +3,12 @@ wrappers, against (1) golden vectors captured from the reference itself, (2) the
 same seeded inputs, (3) size-independent properties at the benchmark size.
 
 Stated tolerances (max|delta| relative to max|reference| of the panel unless noted):
-  float64 path : 1e-10 coefficients, 1e-8 log2 bits where |z| >= 1e-6 max, 1e-10 reductions
+  float64 path : 1e-11 coefficients, 1e-9 log2 bits, 1e-10 reductions.  A bits tolerance needs a magnitude
+                 floor (log2 of a coefficient far below the panel maximum amplifies ANY absolute error, the reference's own
+                 FFT rounding of ~2e-15 max included): 1e-5 max on the hipFFT engine (= the reference's algorithm: 1e-9 bits
+                 there is an absolute error of 7e-15 max), and on the native engines at 2^20 samples the floor the
+                 coefficient contract itself implies, 1e-11 / (1e-9 ln 2) = 1.5e-2 max (BITS_FLOOR_NATIVE64), with the
+                 round-4 check (1e-8 bits from 1e-3 max) kept beside it
   float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-3 max, 1e-4 reductions; at the benchmark
                  length every band is also held to 1e-5 of ITS OWN maximum (weak bands included)
 Band tables, shift indices, STFT shapes / time / frequency axes: bit-exact.
@@ -22,8 +27,9 @@ from quantum_inferno_amd import cwt_atoms, engine, scales_dyadic, styx_cwt, styx
 
 pytestmark = pytest.mark.gpu
 
-TOL = {np.float64: dict(coef=1e-10, bits=1e-8, bits_floor=1e-6, red=1e-10),
+TOL = {np.float64: dict(coef=1e-11, bits=1e-9, bits_floor=1e-5, red=1e-10),
        np.float32: dict(coef=2e-5, bits=1e-3, bits_floor=1e-3, red=1e-4, row=1e-5)}
+BITS_FLOOR_NATIVE64 = 1.5e-2  # coef / (bits ln 2): where the 1e-11 coefficient contract implies 1e-9 bits
 # (measured at 2^20 samples against the reference, tools/measure_parity.py: panel-relative error < 1e-6, every band
 # within 2.4e-6 of its own maximum at orders 3 and 12, bits within 3e-4 above 1e-3 of the panel maximum)
 
@@ -120,7 +126,7 @@ def test_stft_benchmark_shape_vs_reference(golden, dtype):
     assert np.max(np.abs(z[rows] - g[f"z_rows_{dtype}"])) <= tol * zmax
     assert np.max(np.abs(z[:, cols] - g[f"z_cols_{dtype}"])) <= tol * zmax
     big = np.abs(g[f"z_cols_{dtype}"]) >= 1e-3 * zmax
-    assert np.max(np.abs(bits[:, cols] - g[f"bits_cols_{dtype}"])[big]) <= (2e-3 if dtype == "float32" else 1e-8)
+    assert np.max(np.abs(bits[:, cols] - g[f"bits_cols_{dtype}"])[big]) <= (2e-3 if dtype == "float32" else 1e-9)
 
 
 def test_stft_split_kernel_vs_reference(golden):
@@ -164,7 +170,7 @@ def test_stft_2d_batch_and_errors(golden):
     g = golden("stft.npz")
     f, t, z = styx_fft.stft_complex_pow2(g["sig_2d"], 1000.0, 256)
     assert np.array_equal(f, g["f_2d"]) and np.array_equal(t, g["t_2d"])
-    assert z.shape == g["z_2d_alpha025"].shape and relmax(z, g["z_2d_alpha025"]) <= 1e-10
+    assert z.shape == g["z_2d_alpha025"].shape and relmax(z, g["z_2d_alpha025"]) <= 1e-11
     with pytest.raises(ValueError):
         styx_fft.stft_from_sig(np.zeros(1024), 1000.0, 12)  # ref styx_fft.py:42-45
     # Gaussian-window variant against the oracle's spectral helper
@@ -172,7 +178,7 @@ def test_stft_2d_batch_and_errors(golden):
     f2, t2, zg = styx_fft.gtx_complex_pow2(sig, 1000.0, 256)
     k = np.arange(0, 257) - 128.0
     ref = orc.stft_spectral(sig, 1000.0, np.exp(-(k ** 2) / (2 * 64.0 * 64.0))[:-1], 256, 128, 256)
-    assert np.array_equal(t2, ref[1]) and relmax(zg, ref[2]) <= 1e-10
+    assert np.array_equal(t2, ref[1]) and relmax(zg, ref[2]) <= 1e-11
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -238,7 +244,7 @@ def test_atoms_on_any_time_axis_log2_of_tensors_and_short_records():
         f1, t1, z1 = styx_fft.stft_complex_pow2(sig, fs, 512, overlap_points=100)
         f0, t0, z0 = scipy.signal.stft(sig, fs, window=("tukey", 0.25), nperseg=512, noverlap=100, nfft=512, detrend="constant",
                                        return_onesided=True, boundary="zeros", padded=True)
-    assert np.array_equal(f1, f0) and np.allclose(t1, t0, rtol=0, atol=1e-12) and relmax(z1, z0) <= 1e-10
+    assert np.array_equal(f1, f0) and np.allclose(t1, t0, rtol=0, atol=1e-12) and relmax(z1, z0) <= 1e-11
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -247,20 +253,20 @@ def test_tfr_info_vs_reference(golden, dtype):
     tol = TOL[dtype]
     p = g["info_power"].astype(dtype)
     bits, per_time, per_freq = tfr_info.power_dynamics_scaled_bits(p)
-    atol = 1e-9 if dtype == np.float64 else 2e-4
-    assert np.max(np.abs(bits - g["info_bits"])) <= atol * 40
-    assert np.max(np.abs(per_time - g["info_bits_time"])) <= atol * 40
-    assert np.max(np.abs(per_freq - g["info_bits_freq"])) <= atol * 40
-    assert np.max(np.abs(tfr_info.scale_power_bits(p) - g["info_bits"])) <= atol * 40
+    atol = 1e-9 if dtype == np.float64 else 1e-3  # bits within 1e-9 (float64) / 1e-3 (float32)
+    assert np.max(np.abs(bits - g["info_bits"])) <= atol
+    assert np.max(np.abs(per_time - g["info_bits_time"])) <= atol
+    assert np.max(np.abs(per_freq - g["info_bits_freq"])) <= atol
+    assert np.max(np.abs(tfr_info.scale_power_bits(p) - g["info_bits"])) <= atol
     for nm, obj in (("tot", tfr_info.shannon_stft_from_tfr_power(p)), ("time", tfr_info.ShannonStftPerTime(p)),
                     ("freq", tfr_info.ShannonStftPerFreq(p))):
-        assert np.max(np.abs(obj.info - g[f"sh_{nm}_info"])) <= atol * 40, nm
+        assert np.max(np.abs(obj.info - g[f"sh_{nm}_info"])) <= atol, nm
         assert relmax(obj.shannon_bits, g[f"sh_{nm}_bits"]) <= tol["red"], nm
         assert obj.ref_bits == float(g[f"sh_{nm}_ref"])
-        assert np.max(np.abs(obj.isnr - g[f"sh_{nm}_isnr"])) <= atol * 40, nm
+        assert np.max(np.abs(obj.isnr - g[f"sh_{nm}_isnr"])) <= atol, nm
         assert relmax(obj.esnr, g[f"sh_{nm}_esnr"]) <= tol["red"], nm
     # 1-D marginal input and a pdf handed in directly
-    assert np.max(np.abs(tfr_info.scale_power_bits(p.sum(axis=0)) - g["info_bits_time"])) <= atol * 40
+    assert np.max(np.abs(tfr_info.scale_power_bits(p.sum(axis=0)) - g["info_bits_time"])) <= atol
     direct = tfr_info.ShannonStft((g["info_power"] / g["info_power"].sum()).astype(dtype), p.size)
     assert relmax(direct.shannon_bits, g["sh_tot_bits"]) <= tol["red"]
 
@@ -481,15 +487,15 @@ def test_batches_tiles_and_oracle_on_noise():
     ref_c = np.stack([orc.cwt_fft(order, xi, fs)[2] for xi in x])
     ref_s = np.stack([orc.stx_fft(order, xi, fs)[2] for xi in x])
     f, _, c = styx_cwt.cwt_complex_any_scale_pow2(order, x, fs)
-    assert c.shape == ref_c.shape and relmax(c, ref_c) <= 1e-10
+    assert c.shape == ref_c.shape and relmax(c, ref_c) <= 1e-11
     _, _, s = styx_stx.stx_complex_any_scale_pow2(order, x, fs)
-    assert relmax(s, ref_s) <= 1e-10
+    assert relmax(s, ref_s) <= 1e-11
     # tiny workspace: 1 channel x 5 bands per tile
     small = 7 * 2 * n * 16 + len(f) * 4 * 32 + 8192
     plan = _plan_with_all(n, fs, order, np.float64, workspace=small)
     xt = torch.from_numpy(x).cuda()
     r = plan.cwt(xt, coef=True, bits=True, reductions=True)
-    assert relmax(r.coef.cpu().numpy(), ref_c) <= 1e-10
+    assert relmax(r.coef.cpu().numpy(), ref_c) <= 1e-11
     p = np.abs(ref_c) ** 2
     assert np.allclose(r.power_band.cpu().numpy(), p.sum(axis=2), rtol=1e-10)
     assert np.allclose(r.power_time.cpu().numpy(), p.sum(axis=1), rtol=1e-10)
@@ -497,19 +503,19 @@ def test_batches_tiles_and_oracle_on_noise():
     ent = [np.sum(orc.shannon_from_power(pi).shannon_bits) for pi in p]
     assert np.allclose(r.entropy_bits.cpu().numpy(), ent, rtol=1e-10)
     r2 = plan.stx(xt, coef=True, reductions=True)
-    assert relmax(r2.coef.cpu().numpy(), ref_s) <= 1e-10
+    assert relmax(r2.coef.cpu().numpy(), ref_s) <= 1e-11
     zero = plan.cwt(torch.zeros((1, n), dtype=torch.float64, device="cuda"), coef=True, reductions=True)
     assert float(zero.coef.abs().max()) == 0.0 and float(zero.stats[0, 1]) == 0.0
     plan.close()
     # n not a power of two goes through the same path with hipFFT sizes
     m = 3000
     xm = rng.standard_normal(m)
-    assert relmax(styx_cwt.cwt_complex_any_scale_pow2(3, xm, fs)[2], orc.cwt_fft(3, xm, fs)[2]) <= 1e-10
-    assert relmax(styx_stx.stx_complex_any_scale_pow2(3, xm, fs)[2], orc.stx_fft(3, xm, fs)[2]) <= 1e-10
-    assert relmax(cwt_atoms.cwt_chirp_from_sig(xm, fs, 3)[0], orc.cwt_chirp_fft(xm, fs, 3)[0]) <= 1e-10
+    assert relmax(styx_cwt.cwt_complex_any_scale_pow2(3, xm, fs)[2], orc.cwt_fft(3, xm, fs)[2]) <= 1e-11
+    assert relmax(styx_stx.stx_complex_any_scale_pow2(3, xm, fs)[2], orc.stx_fft(3, xm, fs)[2]) <= 1e-11
+    assert relmax(cwt_atoms.cwt_chirp_from_sig(xm, fs, 3)[0], orc.cwt_chirp_fft(xm, fs, 3)[0]) <= 1e-11
     # index_shift != 0 (chirped atoms, complex p)
     ref = orc.cwt_chirp_fft(x[0], fs, 3, index_shift=1.0)[0]
-    assert relmax(cwt_atoms.cwt_chirp_from_sig(x[0], fs, 3, index_shift=1.0)[0], ref) <= 1e-10
+    assert relmax(cwt_atoms.cwt_chirp_from_sig(x[0], fs, 3, index_shift=1.0)[0], ref) <= 1e-11
     with pytest.raises(ValueError):
         styx_cwt.cwt_complex_any_scale_pow2(3, x[0], fs, cwt_type="morlet2")
     with pytest.raises(ValueError):
@@ -622,9 +628,11 @@ def test_float64_native_engine_vs_oracle(golden, order):
         assert np.max(np.abs(got - want)) <= tol["coef"] * scale, (name, order)
         for i, j in enumerate(pick):  # each sampled band also to its own maximum (weak bands carry the rounding of the strong ones)
             assert np.max(np.abs(got[i] - want[i])) <= 5e-9 * np.max(np.abs(want[i])), (name, order, j)
-        # (at 2^20 samples the float64 transforms carry ~2e-12 of the panel maximum: the bits are compared where that is
-        # below the 1e-8 tolerance, |z| >= 1e-3 of the maximum)
-        check_bits(a.bits[0][torch.tensor(pick, device="cuda")].cpu().numpy(), want, dict(bits=tol["bits"], bits_floor=1e-3))
+        # (at 2^20 samples the float64 transforms carry ~1e-12 of the panel maximum: 1e-9 bits where the coefficient
+        # tolerance implies them, and 1e-8 from 1e-3 of the maximum as in round 4)
+        got_bits = a.bits[0][torch.tensor(pick, device="cuda")].cpu().numpy()
+        check_bits(got_bits, want, dict(bits=tol["bits"], bits_floor=BITS_FLOOR_NATIVE64))
+        check_bits(got_bits, want, dict(bits=1e-8, bits_floor=1e-3))
         b = getattr(ref, name)(xt, coef=True, reductions=True)
         worst = float((a.coef - b.coef).abs().amax(dim=2).max()) / scale
         assert worst <= tol["coef"], (name, order, worst)
@@ -881,7 +889,7 @@ def test_general_stockwell_vs_reference(golden, name, kw):
     g = golden("stx_general_n1024.npz")
     tfr, psd, f, f_fft, win = styx_stx.tfr_stx_fft(g["sig"], 1 / 1000.0, n_fft_in=1024, **kw)
     assert np.array_equal(f, g[f"{name}_f"]) and np.array_equal(f_fft, g[f"{name}_ffft"])
-    assert relmax(tfr, g[f"{name}_tfr"]) <= 1e-10
+    assert relmax(tfr, g[f"{name}_tfr"]) <= 1e-11
     assert np.allclose(psd[0], g[f"{name}_psd_row0"], rtol=1e-8, atol=1e-12 * psd.max())
     assert relmax(win[[0, len(f) - 1]], g[f"{name}_win_rows"]) <= 1e-12
     # the padding path the reference documents but cannot run (TypeError upstream): 1000 samples padded to 1024
@@ -891,7 +899,7 @@ def test_general_stockwell_vs_reference(golden, name, kw):
         dict(scale_order_input="order", frequency_min="f_min", frequency_max="f_max", frequency_step="f_step",
              factor_q="q", power_p="p", power_r="r", is_geometric="geometric", is_inferno="inferno")[k]: v
         for k, v in kw.items()})[0][:, :1000]
-    assert t2.shape == ref.shape and relmax(t2, ref) <= 1e-10
+    assert t2.shape == ref.shape and relmax(t2, ref) <= 1e-11
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -899,7 +907,7 @@ def test_welch_vs_reference(golden, dtype):
     """styx_fft.welch_power_pow2."""
     g = golden("stft.npz")
     sig = g[f"sig_n13_fs1000_{dtype}"]
-    tol = 1e-10 if dtype == "float64" else 2e-5
+    tol = 1e-11 if dtype == "float64" else 2e-5
     f, p = styx_fft.welch_power_pow2(sig, 1000.0, 512)
     assert np.array_equal(f, g[f"welch_f_{dtype}"]) and p.dtype == g[f"welch_p_{dtype}"].dtype
     assert relmax(p, g[f"welch_p_{dtype}"]) <= tol
@@ -1361,7 +1369,7 @@ def test_stockwell_rows_behind_the_native_run(dtype, log2n, order):
     assert torch.allclose(a.power_time, b.power_time, rtol=1e-8 if f64 else 1e-3, atol=(1e-11 if f64 else 1e-6) * float(b.power_time.max()))
     assert torch.allclose(a.stats[:, :3], b.stats[:, :3], rtol=1e-9 if f64 else 1e-4)
     big = b.coef.abs() >= 1e-2 * float(b.coef.abs().max())
-    assert float((a.bits - b.bits).abs()[big].max()) <= (1e-8 if f64 else 1e-3)
+    assert float((a.bits - b.bits).abs()[big].max()) <= (1e-9 if f64 else 1e-3)
     pick = [nb - 3, nb - 2, nb - 1]
     _, _, want = orc.stx_fft(order, x[1].astype(np.float64), fs, bands=pick)
     got = a.coef[1][torch.tensor(pick, device="cuda")].cpu().numpy()
