@@ -304,8 +304,8 @@ def stream_bench(args, ctx, cpu):
         ach = insts / (item_ms * 1e6) if insts else None  # wave instructions per nanosecond = G / s
         line["roofline"] = {
             "bound": "fp64-valu" if args.dtype == "f64" else "fp32-valu", "kernel": "all kernels of one streamed item",
-            "achieved": round(ach, 2) if ach else None, "peak": FP64_VALU_PEAK_GINST if args.dtype == "f64" else 2 * FP64_VALU_PEAK_GINST,
-            "unit": "G wave-instructions/s", "frac": round(ach / FP64_VALU_PEAK_GINST, 4) if (ach and args.dtype == "f64") else None,
+            "achieved": round(ach, 2) if ach else None, "peak": FP64_VALU_PEAK_GINST,  # (float32 too: tools/micro/pk_rate.hip measures 4 cycles per wave64 v_fma_f32)
+            "unit": "G wave-instructions/s", "frac": round(ach / FP64_VALU_PEAK_GINST, 4) if ach else None,
             "traffic": tdata.get(f"item:{args.dtype}:n{args.log2n}:o{order:g}:c{n_ch}:stream"),
             "valu_wave_instructions_per_item": insts,
             "valu_instructions_per_output": round(insts * 64 / points_item, 2) if insts else None,

@@ -61,17 +61,12 @@ typedef enum {
   QI_ENGINE_NATIVE = 2  /* hand-written LDS FFT passes with fused multiply and epilogue   */
 } qi_engine;
 
-/* qi_plan_desc.flags */
-#define QI_PLAN_GRAPH 1 /* qi_cwt_stx calls of one or two float32 records are captured once per set of buffers as a HIP graph
-                           whose block launch is a branch beside the forward / coarse / interpolation chain, and replayed
-                           afterwards (results identical to the eager launches: the same kernels on the same data) */
-
 typedef struct {
   int64_t n;               /* samples per record (any n >= 2 for hipFFT; 2^k for native)  */
   int32_t dtype;           /* qi_dtype                                                     */
   int32_t device;          /* HIP device ordinal                                           */
   int32_t engine;          /* qi_engine                                                    */
-  int32_t flags;           /* QI_PLAN_* bits (0 = defaults)                                */
+  int32_t flags;           /* reserved: must be 0 (qi_plan_create rejects anything else)   */
   int64_t workspace_bytes; /* scratch budget owned by the plan; 0 = default (2 GiB)        */
 } qi_plan_desc;
 

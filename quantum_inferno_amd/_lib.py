@@ -11,7 +11,6 @@ LIB_PATH = os.environ.get("QI_TFR_LIB") or os.path.join(_HERE, "libqi_tfr.so")  
 QI_F32, QI_F64 = 0, 1
 QI_BANK_STYX, QI_BANK_ATOMS, QI_TABLE_STX = 0, 1, 2
 QI_ENGINE_AUTO, QI_ENGINE_HIPFFT, QI_ENGINE_NATIVE = 0, 1, 2
-QI_PLAN_GRAPH = 1  # qi_plan_desc.flags: qi_cwt_stx calls of one or two float32 records run as a captured graph
 STAGES = ("forward", "multiply", "inverse", "epilogue", "pass1", "pass2", "block", "zoom", "zoom_coarse")
 
 

@@ -24,6 +24,7 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   QI_REQUIRE(desc->n >= 2 && desc->n <= (1ll << 28), "n = %lld out of range", (long long)desc->n);
   QI_REQUIRE(desc->dtype == QI_F32 || desc->dtype == QI_F64, "bad dtype %d", desc->dtype);
   QI_REQUIRE(desc->engine >= QI_ENGINE_AUTO && desc->engine <= QI_ENGINE_NATIVE, "bad engine %d", desc->engine);
+  QI_REQUIRE(desc->flags == 0, "qi_plan_desc.flags = %d: the field is reserved and must be 0", desc->flags);
   if (desc->engine == QI_ENGINE_NATIVE && !(is_pow2(desc->n) && desc->n >= (1 << 18) &&
                                             (desc->dtype == QI_F32 || desc->n == (1 << 20)))) {
     set_error("native engine: float32 records of a power-of-two length >= 2^18, float64 records of 2^20 samples (got n = %lld, dtype %d)",
@@ -58,14 +59,8 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_BLOCK")) p->native_block = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM")) p->native_zoom = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_ZOOM_LEVELS")) p->native_zoom_max_level = atoi(e);
-  if (const char* e = tune_env("QI_NATIVE_PAIR")) p->native_pair = atoi(e);
-  p->native_graph = (desc->flags & QI_PLAN_GRAPH) ? 1 : 0;
-  if (const char* e = tune_env("QI_NATIVE_GRAPH")) p->native_graph = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_SPLIT")) p->native_split = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_FUSE")) p->native_fuse = atoi(e);
-#ifdef QI_BLK_LZ
-  if (const char* e = tune_env("QI_NATIVE_BLK_LZ")) p->native_blk_lz = atoi(e);
-#endif
   if (const char* e = tune_env("QI_NATIVE_F64")) p->native_f64 = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64")) p->native_z64 = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_FINE")) p->native_z64_fine = atoi(e);
@@ -105,11 +100,6 @@ int qi_plan_destroy(qi_plan* p) {
   (void)hipDeviceSynchronize();
   p->fft.clear();
   p->prof.clear();
-  for (auto& ge : p->graphs) {
-    if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
-    if (ge.graph) (void)hipGraphDestroy(ge.graph);
-  }
-  p->graphs.clear();
 #ifdef QI_NATIVE_STAMPS
   if (p->stamps) {
     std::vector<unsigned long long> h(65536 * 8);
@@ -164,8 +154,6 @@ int qi_plan_destroy(qi_plan* p) {
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-  if (p->ev_parts) (void)hipEventDestroy(p->ev_parts);
-  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   for (auto& per_cut : p->d_band_slots)
     for (auto* b : per_cut)
       if (b) (void)hipFree(b);
@@ -180,7 +168,6 @@ int qi_plan_destroy(qi_plan* p) {
       if (w) (void)hipFree(w);
   if (p->d_edge) (void)hipFree(p->d_edge);
   if (p->split_bank) (void)hipFree(p->split_bank);
-  if (p->d_lz_w) (void)hipFree(p->d_lz_w);
   if (p->d_split_bands) (void)hipFree(p->d_split_bands);
   for (auto* d : p->d_dual)
     if (d) (void)hipFree(d);
@@ -387,9 +374,11 @@ int64_t qi_plan_stage_bands(const qi_plan* p, int which, int stage) {
   int64_t blk = 0;
   if (which != 1 && p->blk[which].ready) blk = p->blk[which].rows;
   const int64_t zoom = p->nat[which].nzoom + p->nat[which].nz64;
+  const int64_t left = which == 2 ? p->stx_left_n : 0;  // rows the hipFFT engine's pass behind the native run produces
   if (stage == QI_STAGE_BLOCK) return blk;
   if (stage == QI_STAGE_ZOOM) return zoom;
-  return stage == QI_STAGE_PASS2 ? total - blk - zoom : 0;
+  if (stage == QI_STAGE_INVERSE) return left;
+  return stage == QI_STAGE_PASS2 ? total - blk - zoom - left : 0;
 }
 
 int qi_plan_profile(qi_plan* p, int enable) {
@@ -493,90 +482,6 @@ int qi_cwt_stx(qi_plan* p, int bank, const void* sig, int64_t C, const qi_tfr_ou
       p->tile_cache.flags = flags;
       p->tile_cache.gen = p->table_gen;
       p->tile_cache.tile = tile;
-    }
-    // One or two records: six short launches, of which the block launch needs nothing the others produce.  As a captured
-    // graph (QI_PLAN_GRAPH) it is a branch beside the forward / coarse / interpolation chain, joined in front of the split
-    // bands' edge items and the tail; the graph is captured on the second call with the same buffers and replayed afterwards.
-    // (Calls whose stages are being timed run eagerly.)
-    const bool timed = p->prof.on && (p->prof.period <= 1 || p->prof.tick % p->prof.period == 0 ||
-                                      (p->prof.tick + 1) % p->prof.period == 0);
-    if (p->native_graph && tile >= C && C <= 2 && !timed) {
-      qi_plan::GraphEntry* ge = nullptr;
-      auto same = [](const qi_tfr_out& a, const qi_tfr_out& b) {
-        return a.coef == b.coef && a.bits == b.bits && a.power_band == b.power_band && a.power_time == b.power_time &&
-               a.stats == b.stats && a.power_scale == b.power_scale && a.eps == b.eps;
-      };
-      for (auto& e : p->graphs)
-        if (e.sig == sig && e.C == C && e.gen == p->table_gen && same(e.oc, *out_cwt) && same(e.os, *out_stx)) ge = &e;
-      if (!ge) {
-        if (p->graphs.size() >= 8) {  // (a caller that walks through many buffers: forget the oldest)
-          if (p->graphs.front().exec) (void)hipGraphExecDestroy(p->graphs.front().exec);
-          if (p->graphs.front().graph) (void)hipGraphDestroy(p->graphs.front().graph);
-          p->graphs.erase(p->graphs.begin());
-        }
-        p->graphs.emplace_back();
-        ge = &p->graphs.back();
-        ge->sig = sig;
-        ge->C = C;
-        ge->oc = *out_cwt;
-        ge->os = *out_stx;
-        ge->gen = p->table_gen;
-      }
-      if (ge->exec) {
-        p->prof.unchain();
-        p->prof.unchain();
-        QI_HIP(hipGraphLaunch(ge->exec, st));
-        return QI_OK;
-      }
-      if (++ge->seen >= 2) {
-        if (!p->side) {
-          QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-          QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-          QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-        }
-        if (!p->ev_parts) QI_HIP(hipEventCreateWithFlags(&p->ev_parts, hipEventDisableTiming));
-        if (!p->cap_stream) QI_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
-        hipStream_t caller = st;
-        st = p->cap_stream;  // (captured on a stream of the plan, launched on the caller's)
-        QI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        int rc = QI_OK;
-        p->capturing = true;  // (run_native forks to the side stream behind the clearing of the first table's partial sums)
-        p->carry.active = false;
-        p->carry.has_zoom = false;
-        if (rc == QI_OK) rc = run_native<float>(p, bank, sig, C, out_cwt, st, false, &p->carry, nullptr);
-        if (rc == QI_OK) {
-          rc = run_native<float>(p, 2, sig, C, out_stx, st, /*may_share=*/true, nullptr, &p->carry);
-          if (p->carry.active) {
-            const int rc2 = flush_carry(p, &p->carry, st);
-            if (rc == QI_OK) rc = rc2;
-          }
-        }
-        p->capturing = false;
-        p->shared_valid = false;
-        // (whatever the runs did with the side stream: it is joined before the capture ends)
-        hipStreamCaptureStatus side_status = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(p->side, &side_status) == hipSuccess && side_status == hipStreamCaptureStatusActive)
-          if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(st, p->ev_join, 0) != hipSuccess) (void)hipGetLastError();
-        hipGraph_t graph = nullptr;
-        const hipError_t ec = hipStreamEndCapture(st, &graph);
-        if (rc == QI_OK && (ec != hipSuccess || !graph)) {
-          set_error("capturing qi_cwt_stx failed: %s", hipGetErrorString(ec));
-          rc = QI_ERR_HIP;
-        }
-        if (rc == QI_OK && hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-          set_error("instantiating the graph of qi_cwt_stx failed");
-          ge->exec = nullptr;
-          rc = QI_ERR_HIP;
-        }
-        if (rc != QI_OK) {
-          if (graph) (void)hipGraphDestroy(graph);
-          (void)hipGetLastError();
-          return rc;
-        }
-        ge->graph = graph;
-        QI_HIP(hipGraphLaunch(ge->exec, caller));
-        return QI_OK;
-      }
     }
     if (tile >= 1) {
       const int64_t n = p->n, B0 = p->nb[bank], B2 = p->nb_stx;

@@ -610,300 +610,6 @@ __device__ __forceinline__ void block_item(const BlockArgs<T>& a, const BlockIte
                                         s_red, w);
 }
 
-#ifdef QI_BLK_LZ  // experiment of round 3 (DESIGN s8c): measured no faster than the sparse 4096-point path; not in the product build
-// ---- local zoom: the narrow block bands at the decimated rate ---------------------------------------------------------
-// A block band whose filter spectrum spans K <= 4096 / (4 D) bins is a slow envelope (on a carrier, for the Gabor banks):
-// sampled every D-th output it is still oversampled >= 4 times.  Those samples are exactly the outputs t = 0 (mod D) of the
-// inverse transform, i.e. R = 16 / D of the sixteen 256-point sub-transforms that follow its first radix-16 pass
-// (t = q2 + 16 s: one sub-transform per q2).  So a GROUP of D bands shares ONE run of the two LDS passes of fft4096_tail:
-// row b R + r of the first exchange image holds v[q2 = r D] of band slot b (the head is sparse_head16's y om^q2, only R
-// powers), pass 2 and pass 3 run unchanged on all 256 threads, and thread (q2t, q1) ends up with the coarse samples
-// c = R q1 + r + 16 R q0 of band slot b = q2t / R.  They are taken to baseband there -- Stockwell: the demodulation
-// exp(-2 pi i idx t / n) itself, 16 products per thread and GROUP instead of 14 per thread and band; Gabor: the carrier
-// exp(-2 pi i kc u / 4096) of a centre bin kc = 0 (mod 16) -- and written to LDS as [slot][4096 / D]; every output is then
-// 10 real taps (the zoom engine's band-optimal interpolator, exact at the Chebyshev nodes of [-pi / 4, pi / 4]) on the
-// ten coarse samples around it, read with constant offsets from one address, times the carrier for the Gabor banks.
-// Per band: 1.5 barriers instead of 4 and about half the instructions of the 4096-point inverse transform.
-template <typename T, int WQ, int LOG2D, bool DEMOD, bool COEF, bool BITS>
-__device__ __forceinline__ void lz_bands(const BlockArgs<T>& a, int32_t blk_i, int32_t band_first, int32_t band_count,
-                                         int32_t plane, int32_t stat_slot, cplx<T> (&S)[16], cplx<T>* __restrict__ buf,
-                                         const cplx<T>* __restrict__ tw256, double (*s_lz)[kBlkThreads / kWave],
-                                         int32_t* __restrict__ s_lz_band, cplx<T> w) {
-  constexpr int D = 1 << LOG2D, R = 16 / D, M = kBlk / D, G = D, NT = kBlkLzTaps;
-  constexpr int W = 256 * WQ, V = kBlk - 2 * W, NOUT = 16 - 2 * WQ, NW = kBlkThreads / kWave;
-  static_assert(G * M <= kBlkBuf && G <= 8, "the coarse samples of a group live in the exchange buffer");
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  const int col = kWave * wv + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);  // fft4096's column order
-  const int64_t blk = blk_i, ch = blockIdx.z, n = a.n;
-  const int64_t t0 = blk * V - W;  // record samples [t0, t0 + 4096), outputs [t0 + W, t0 + W + V)
-  if (!DEMOD) {  // half-sample offset of the Gabor atoms (see block_bands)
-    float sn, cs;
-    sincospif(-(float)col * (1.0f / (float)kBlk), &sn, &cs);
-    rotate_rows16<T>(S, mk<T>((T)cs, (T)sn), std::make_integer_sequence<int, 16>{});
-  }
-  // this thread's outputs: the pairs (u, u + 1), u = u0 + 256 (i + hi), i = 0, 2, ... (block_bands' pair layout)
-  const int hi = lane >> 5, u0 = W + kWave * wv + 2 * (lane & 31);
-  T wa[NT], wb[NT];  // taps of the phases u mod D and (u + 1) mod D
-  {
-    const float* __restrict__ wt = a.lz_w + (LOG2D - 2) * 8 * NT + (u0 & (D - 1)) * NT;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      wa[j] = (T)wt[j];
-      wb[j] = (T)wt[NT + j];
-    }
-  }
-  const int qbase = u0 / D + (256 / D) * hi - (NT / 2 - 1);  // first window sample of the first pair
-  T col_p[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) col_p[i] = T(0);
-  T mx = T(0);
-  double plogp = 0.0;
-  const uint32_t tb_pair = (uint32_t)(t0 + u0) + (hi ? 256u : 0u);
-  const int pos = col ^ ((col >> 4) & 1);  // fft4096_tail's first exchange image
-  const int k0 = tid & 15, q2t = tid >> 4;
-  int pend = 0;  // bands of the previous group whose wave sums wait in s_lz
-
-  for (int g0 = 0; g0 < band_count; g0 += G) {
-    const int nb = band_count - g0 < G ? band_count - g0 : G;
-    __syncthreads();  // the readers of buf (forward transform, the previous group's interpolation) are done
-    // ---- heads: v[q2 = r D] = y om^(r D) of every band of the group
-    for (int b = 0; b < nb; ++b) {
-      const BlockBand bd = a.bands[band_first + g0 + b];
-      const int kres = (col - bd.klo) & 255;
-      const int k = (bd.klo + kres) & (kBlk - 1);
-      const bool first = (k >> 8) == (bd.klo >> 8);
-      const cplx<T> x = pick_pair16<T>(S, __builtin_amdgcn_readfirstlane(bd.klo >> 8), first);
-      T dk = (T)(k - bd.kappa_int) - (T)bd.kappa_frac;
-      T amp = (T)bd.amp;
-      if (dk > (T)(kBlk / 2)) {
-        dk -= (T)kBlk;
-        if (!DEMOD) amp = -amp;
-      }
-      if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
-      const T e = (T)bd.cw * dk;
-      const T r = amp * fast_exp2(-e * e);
-      cplx<T> wq = w;
-      asm volatile("" : "+v"(wq.x), "+v"(wq.y));
-      cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
-#pragma unroll
-      for (int q = 0; q < LOG2D; ++q) om = cmul(om, om);  // om^D
-      cplx<T> vr = mk<T>(x.x * r, x.y * r);
-      cplx<T>* __restrict__ row = buf + (b * R) * kBlkRow1 + pos;
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr) {
-        row[rr * kBlkRow1] = vr;
-        if (rr + 1 < R) vr = cmul(vr, om);
-      }
-    }
-    __syncthreads();
-    if (pend > 0 && tid < pend && a.part_band) {
-      double r = 0.0;
-      for (int q = 0; q < NW; ++q) r += s_lz[tid][q];
-      a.part_band[((int64_t)ch * a.panel_bands + s_lz_band[tid]) * a.nblk + blk] = r;
-    }
-    // ---- the two LDS passes of fft4096_tail, rows = (band slot, r)
-    cplx<T> v[16];
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) v[k1] = buf[q2t * kBlkRow1 + 16 * k1 + (k0 ^ (k1 & 1))];
-    fft_reg<T, 16, 1>(v);
-#pragma unroll
-    for (int q1 = 1; q1 < 16; ++q1) v[brev(q1, 4)] = cmul(v[brev(q1, 4)], tw256[(k0 * q1) & 255]);
-    __syncthreads();
-#pragma unroll
-    for (int q1 = 0; q1 < 16; ++q1) buf[k0 * kBlkPad + 16 * q2t + q1] = v[brev(q1, 4)];  // to thread 16 q2t + q1
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = buf[k * kBlkPad + tid];
-    fft_reg<T, 16, 1>(v);  // v[brev(q0)] = sample u = colp + 256 q0 of band slot bs
-    const int q1p = tid & 15, rr = q2t & (R - 1), bs = q2t >> (4 - LOG2D);
-    const int colp = 16 * q1p + D * rr;
-    {
-      const BlockBand* __restrict__ bp = a.bands + band_first + g0 + (bs < nb ? bs : nb - 1);
-      if (DEMOD) {
-        // exp(-2 pi i idx (t0 + u) / n) at q0 = 0 from the exact integer phase, the other fifteen by binary products with
-        // r^(2^k) (depth <= 4 roundings)
-        const uint32_t m = (0u - (uint32_t)bp->shift * (uint32_t)(t0 + colp)) & (uint32_t)(n - 1);
-        float sn, cs;
-        sincospif((float)m * a.two_over_n, &sn, &cs);
-        const cplx<T> R1 = mk<T>((T)bp->rot[0], (T)bp->rot[1]), R2 = mk<T>((T)bp->rot[2], (T)bp->rot[3]);
-        const cplx<T> R4 = mk<T>((T)bp->rot[4], (T)bp->rot[5]), R8 = mk<T>((T)bp->rot[6], (T)bp->rot[7]);
-        const cplx<T> s0 = mk<T>((T)cs, (T)sn);
-#define QI_LZ_ROW(S4)                                                    \
-  {                                                                      \
-    const cplx<T> b0 = (S4);                                             \
-    const cplx<T> b1 = cmul_rn(b0, R1), b2 = cmul_rn(b0, R2);            \
-    const cplx<T> b3 = cmul_rn(b2, R1);                                  \
-    v[brev(q4 + 0, 4)] = cmul_rn(v[brev(q4 + 0, 4)], b0);                \
-    v[brev(q4 + 1, 4)] = cmul_rn(v[brev(q4 + 1, 4)], b1);                \
-    v[brev(q4 + 2, 4)] = cmul_rn(v[brev(q4 + 2, 4)], b2);                \
-    v[brev(q4 + 3, 4)] = cmul_rn(v[brev(q4 + 3, 4)], b3);                \
-  }
-        const cplx<T> s4 = cmul_rn(s0, R4), s8 = cmul_rn(s0, R8);
-        const cplx<T> s12 = cmul_rn(s8, R4);
-        { constexpr int q4 = 0; QI_LZ_ROW(s0) }
-        { constexpr int q4 = 4; QI_LZ_ROW(s4) }
-        { constexpr int q4 = 8; QI_LZ_ROW(s8) }
-        { constexpr int q4 = 12; QI_LZ_ROW(s12) }
-#undef QI_LZ_ROW
-      } else {
-        // exp(-2 pi i kc u / 4096), kc = 0 (mod 16): the same for the sixteen samples of the thread
-        const uint32_t m = (0u - (uint32_t)bp->kc * (uint32_t)colp) & (uint32_t)(kBlk - 1);
-        float sn, cs;
-        sincospif((float)m * (2.0f / (float)kBlk), &sn, &cs);
-        const cplx<T> g = mk<T>((T)cs, (T)sn);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = cmul_rn(v[q], g);
-      }
-    }
-    __syncthreads();  // the second exchange image has been read
-    {
-      cplx<T>* __restrict__ e = buf + bs * M + R * q1p + rr;
-#pragma unroll
-      for (int q0 = 0; q0 < 16; ++q0) e[16 * R * q0] = v[brev(q0, 4)];
-    }
-    __syncthreads();
-    // ---- outputs of every band of the group
-    for (int b = 0; b < nb; ++b) {
-      const BlockBand bd = a.bands[band_first + g0 + b];
-      cplx<T> A0 = mk<T>(T(1), T(0)), A1 = A0;
-      if (!DEMOD) {  // carrier exp(2 pi i kc u / 4096) of the even and of the odd sample of this thread's pairs
-        const uint32_t m = ((uint32_t)bd.kc * (uint32_t)u0) & (uint32_t)(kBlk - 1);
-        float sn, cs;
-        sincospif((float)m * (2.0f / (float)kBlk), &sn, &cs);
-        A0 = mk<T>((T)cs, (T)sn);
-        A1 = cmul_rn(A0, mk<T>((T)bd.rot_lz[0], (T)bd.rot_lz[1]));
-      }
-      const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
-      char* __restrict__ coef_row = reinterpret_cast<char*>(a.coef ? a.coef + orow : nullptr);
-      char* __restrict__ bits_row = reinterpret_cast<char*>(a.bits ? a.bits + orow : nullptr);
-      const cplx<T>* __restrict__ eb = buf + b * M + qbase;
-      uint32_t tp = tb_pair;
-      asm volatile("" : "+v"(tp));
-      T rowacc = T(0), pl = T(0);
-      auto finish_band = [&](auto guard) {
-        constexpr bool GUARD = decltype(guard)::value;
-#pragma unroll
-        for (int i = 0; i < NOUT; i += 2) {
-          cplx<T> z[2] = {mk<T>(T(0), T(0)), mk<T>(T(0), T(0))};
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const cplx<T> sm = eb[(256 / D) * i + j];
-            z[0].x = fmaf(wa[j], sm.x, z[0].x);
-            z[0].y = fmaf(wa[j], sm.y, z[0].y);
-            z[1].x = fmaf(wb[j], sm.x, z[1].x);
-            z[1].y = fmaf(wb[j], sm.y, z[1].y);
-          }
-          if (!DEMOD) {
-            z[0] = cmul_rn(z[0], A0);
-            z[1] = cmul_rn(z[1], A1);
-          }
-          const uint32_t tt = tp + 256u * (uint32_t)i;  // first sample of this lane's pair
-          const bool inside = !GUARD || tt < (uint32_t)n;
-          T lg[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const T m2 = norm2(z[h].x, z[h].y);
-            if (BITS) lg[h] = log2_t(sqrt_t(m2) + a.eps);
-            const T p = inside ? mul_rn(a.power_scale, m2) : T(0);
-            col_p[i + h] += p;
-            rowacc += p;
-            mx = max_t(mx, p);
-            pl += plog2p(p);
-          }
-          if (COEF && inside)
-            stream_store(reinterpret_cast<float4*>(coef_row + (size_t)(tt * (uint32_t)sizeof(cplx<T>))),
-                         make_float4(z[0].x, z[0].y, z[1].x, z[1].y));
-          if (BITS && inside) *reinterpret_cast<float2*>(bits_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(lg[0], lg[1]);
-        }
-      };
-      if (t0 + W + V > n) finish_band(std::true_type{});
-      else finish_band(std::false_type{});
-      plogp += (double)pl;
-      if (a.part_band) {
-        const double r = wave_sum((double)rowacc);
-        if (lane == 0) s_lz[b][wv] = r;
-        if (tid == 0) s_lz_band[b] = bd.out_band;
-      }
-    }
-    pend = nb;
-  }
-
-  T tot = T(0);
-  char* __restrict__ time_row = reinterpret_cast<char*>(
-      a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + plane) * n : nullptr);
-#pragma unroll
-  for (int i = 0; i < NOUT; i += 2) {
-    tot += col_p[i] + col_p[i + 1];
-    const uint32_t tt = tb_pair + 256u * (uint32_t)i;
-    if (time_row && tt < (uint32_t)n)
-      *reinterpret_cast<float2*>(time_row + (size_t)(tt * (uint32_t)sizeof(T))) = make_float2(col_p[i], col_p[i + 1]);
-  }
-  const double r0 = wave_max((double)mx), r1 = wave_sum((double)tot), r2 = wave_sum(plogp);
-  __syncthreads();  // the last group's wave sums are visible; buf is free
-  if (pend > 0 && tid < pend && a.part_band) {
-    double r = 0.0;
-    for (int q = 0; q < NW; ++q) r += s_lz[tid][q];
-    a.part_band[((int64_t)ch * a.panel_bands + s_lz_band[tid]) * a.nblk + blk] = r;
-  }
-  if (a.part_stat) {
-    double* fin = reinterpret_cast<double*>(buf);
-    if (lane == 0) {
-      fin[wv] = r0;
-      fin[NW + wv] = r1;
-      fin[2 * NW + wv] = r2;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double m = 0.0, s1 = 0.0, s2 = 0.0;
-      for (int q = 0; q < NW; ++q) {
-        m = fin[q] > m ? fin[q] : m;
-        s1 += fin[NW + q];
-        s2 += fin[2 * NW + q];
-      }
-      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + a.stat_base + stat_slot) * 3;
-      o[0] = m;
-      o[1] = s1;
-      o[2] = s2;
-    }
-  }
-}
-
-template <typename T, int WQ, int LOG2D, bool DEMOD, bool COEF, bool BITS>
-__device__ __forceinline__ void lz_item(const BlockArgs<T>& a, const BlockItem& it, cplx<T>* __restrict__ buf,
-                                        const cplx<T>* __restrict__ tw256, double (*s_lz)[kBlkThreads / kWave],
-                                        int32_t* __restrict__ s_lz_band, cplx<T> w) {
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
-  cplx<T> S[16];
-  block_forward<T, DEMOD>(a.sig + (int64_t)blockIdx.z * a.n, a.n, (int64_t)it.block * (kBlk - 512 * WQ) - 256 * WQ, S, buf, tw256,
-                          w, tid, col);
-  lz_bands<T, WQ, LOG2D, DEMOD, COEF, BITS>(a, it.block, it.band_first, it.band_count, it.plane, it.stat_slot, S, buf, tw256,
-                                            s_lz, s_lz_band, w);
-}
-
-// joint launch: the Stockwell bands and the styx bands of the same block (see dual_item)
-template <typename T, int WQ, int LOG2D, bool COEF, bool BITS>
-__device__ __forceinline__ void lz_dual_item(const BlockArgs<T>& a0, const BlockArgs<T>& a2, const DualItem& it,
-                                             cplx<T>* __restrict__ buf, const cplx<T>* __restrict__ tw256,
-                                             double (*s_lz)[kBlkThreads / kWave], int32_t* __restrict__ s_lz_band, cplx<T> w) {
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  const int col = (tid & ~(kWave - 1)) + (lane < 32 ? 2 * lane : 2 * (lane - 32) + 1);
-  const int64_t n = a0.n, t0 = (int64_t)it.block * (kBlk - 512 * WQ) - 256 * WQ;
-  const bool inside = t0 >= 0 && t0 + kBlk <= n;
-  const T* sig = a0.sig + (int64_t)blockIdx.z * n;
-  cplx<T> S[16];
-  if (it.count2 > 0 || inside) block_forward<T, true>(sig, n, t0, S, buf, tw256, w, tid, col);
-  if (it.count2 > 0)
-    lz_bands<T, WQ, LOG2D, true, COEF, BITS>(a2, it.block, it.first2, it.count2, it.plane2, it.slot2, S, buf, tw256, s_lz,
-                                             s_lz_band, w);
-  if (it.count0 > 0) {
-    if (!inside) block_forward<T, false>(sig, n, t0, S, buf, tw256, w, tid, col);
-    lz_bands<T, WQ, LOG2D, false, COEF, BITS>(a0, it.block, it.first0, it.count0, it.plane0, it.slot0, S, buf, tw256, s_lz,
-                                              s_lz_band, w);
-  }
-}
-
-#endif  // QI_BLK_LZ
 
 // ---- long blocks: 8192 record samples, the narrow Gaussian bands of the 1024-sample reach group ----------------------
 // Half of a 4096-sample block of that group is overlap.  An 8192-sample block keeps 6144 of its outputs (75 %) and costs
@@ -1340,10 +1046,6 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   __shared__ double s_red[2][kBlkThreads / kWave];
-#ifdef QI_BLK_LZ
-  __shared__ double s_lz[8][kBlkThreads / kWave];
-  __shared__ int32_t s_lz_band[8];
-#endif
   const int tid = threadIdx.x;
   {
     float s, c;
@@ -1373,10 +1075,6 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block(BlockArgs<T
   switch (it.wq) {
     case 1: block_item<T, 1, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
     case 2: block_item<T, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
-#ifdef QI_BLK_LZ
-    case kBlkLzA: lz_item<T, 2, 2, DEMOD, COEF, BITS>(a, it, buf, tw256, s_lz, s_lz_band, w); break;
-    case kBlkLzB: lz_item<T, 4, 3, DEMOD, COEF, BITS>(a, it, buf, tw256, s_lz, s_lz_band, w); break;
-#endif
     default: block_item<T, 4, DEMOD, COEF, BITS>(a, it, buf, tw256, s_red, w); break;
   }
 }
@@ -1612,10 +1310,6 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
   __shared__ cplx<T> buf[kBlkBuf];
   __shared__ cplx<T> tw256[256];
   __shared__ double s_red[2][kBlkThreads / kWave];
-#ifdef QI_BLK_LZ
-  __shared__ double s_lz[8][kBlkThreads / kWave];
-  __shared__ int32_t s_lz_band[8];
-#endif
   const int tid = threadIdx.x;
   {
     float s, c;
@@ -1645,10 +1339,6 @@ __global__ void __launch_bounds__(kBlkThreads, QI_BLK_WAVES) k_block_dual(BlockA
     switch (it.wq) {
       case 1: dual_item<T, 1, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
       case 2: dual_item<T, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
-#ifdef QI_BLK_LZ
-      case kBlkLzA: lz_dual_item<T, 2, 2, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
-      case kBlkLzB: lz_dual_item<T, 4, 3, COEF, BITS>(a0, a2, it, buf, tw256, s_lz, s_lz_band, w); break;
-#endif
       default: dual_item<T, 4, COEF, BITS>(a0, a2, it, buf, tw256, s_red, w); break;
     }
   }
@@ -2010,6 +1700,12 @@ int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channe
     QI_LAUNCH_CHECK();
     if (beside) QI_HIP(hipEventRecord(join, side));
   }
+  // (whatever fails below: the caller's stream still waits for the side stream's launch -- its rows and partial slots must
+  // not be left unordered against the next call's reuse of the scratch)
+  struct Rejoin {
+    hipStream_t st; hipEvent_t join; bool on;
+    ~Rejoin() { if (on && hipStreamWaitEvent(st, join, 0) != hipSuccess) (void)hipGetLastError(); }
+  } rejoin{st, join, beside};
   if (a.nitems > 0) {
     dim3 grid((unsigned)a.nitems, 1, (unsigned)n_channels);
     QI_TRY((demod ? launch_block64_v<true>(a, grid, st) : launch_block64_v<false>(a, grid, st)));
@@ -2019,7 +1715,6 @@ int launch_block<double>(const BlockArgs<double>& a, int demod, int64_t n_channe
     QI_E64_ALL(2, grid, items, st);
     QI_LAUNCH_CHECK();
   }
-  if (beside) QI_HIP(hipStreamWaitEvent(st, join, 0));
 #undef QI_E64_ALL
 #undef QI_E64
   return QI_OK;

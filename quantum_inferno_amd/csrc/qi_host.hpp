@@ -328,28 +328,6 @@ struct qi_plan {
   int native_zoom_wgs_joint = 768;   // the same budget per table in the joint launch of qi_cwt_stx (512 .. 1024 measured within 1.5 %)
   int native_zoom_wgs = 0;      // > 0: workgroups of a zoom launch, dealt to the levels by work (measured: 1.5 % slower than the per-level rule)
   float* d_zoom_w[native::kZoomClasses][2] = {};  // interpolation weights [class][lane offset]
-  // the block engine needs only the records, not their spectra: its launch runs on a side stream, concurrently with
-  // the forward transform / pass 1 / coarse zoom stages, which leave most of the chip idle
-  int native_overlap = 0;  // measured: no gain (the block launch fills the chip by itself), kept as an option
-  // qi_cwt_stx as a captured graph (QI_PLAN_GRAPH): one entry per set of caller buffers
-  struct GraphEntry {
-    const void* sig = nullptr;
-    int64_t C = 0;
-    qi_tfr_out oc{}, os{};
-    uint64_t gen = 0;
-    int seen = 0;  // calls with this key so far (the first runs eagerly: lazy set-up -- item lists, function attributes)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-  };
-  std::vector<GraphEntry> graphs;
-  int native_graph = 0;     // QI_PLAN_GRAPH / QI_NATIVE_GRAPH
-  hipStream_t cap_stream = nullptr;  // the stream a call is captured on (the caller's may be the legacy default stream, which cannot capture)
-  bool capturing = false;   // inside the capture of a qi_cwt_stx call: the fork to the side stream was recorded at its start
-  int native_pair = 0;     // qi_cwt_stx: the joint block launch runs beside the zoom engine's launches (side stream).  Measured:
-                           // +1.5 % at 16 records x 167 bands, -0.5 % at one record -- both kernels are bound by vector issue and
-                           // by registers (3-4 waves per SIMD either way), so sharing the chip gains nothing; kept as an option.
-                           // 3: the fork as early as in a captured call, 4 / 5: the side stream at the lowest / highest priority
-                           // (round 4, one record: 0.2552 / 0.2572 / 0.2633 ms against 0.2460 serial)
   int native_z64 = 1;      // float64: narrow-spectrum bands at the decimated rate (coarse inverse FFT + 16-tap interpolation)
   int native_z64_levels = native::kZ64Levels;  // ... on coarse grids of Lf / 64 ... Lf / (64 >> (levels - 1)) samples
   double* d_z64_w[native::kZ64Levels] = {};  // interpolation weights per coarse-grid level
@@ -371,7 +349,7 @@ struct qi_plan {
                                 // (no gather launch, two passes over the coarse storage fewer, the loads of a thread's sixteen
                                 // inputs batched: -35 % of that stage at 16 records, -20 % at one); 0: never
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_parts = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // split bands of the styx bank (atoms longer than the record): zoom engine + edge pieces, see split_taper
   int native_split = 1;        // 0: such bands stay on the two-pass kernels
   int64_t native_split_e = 1024;  // taper length in samples (512, 1024 or 2048: the edge pieces' reach group)
@@ -388,13 +366,6 @@ struct qi_plan {
   int native_fuse = 4;         // qi_cwt_stx: 1 the block launches and the tails of the two transforms go out back to back, 2 as one
                                // launch each, 3 also the gather and the coarse stage of the zoom engine, 4 and its interpolation
   int native_blk_narrow = 1;   // block bands whose filter spectrum spans <= 256 bins skip the first radix-16 pass of the inverse transform
-#ifdef QI_BLK_LZ
-  int native_blk_lz = 3;
-#else
-  int native_blk_lz = 0;
-#endif
-  // ^ local zoom, an experiment that needs a -DQI_BLK_LZ build (bit 0: the 512-sample reach group, bit 1: the 1024-sample group): block bands of the 512- / 1024-sample reach groups with <= 256 / 128 - 16 spectrum bins from coarse samples + interpolation (qi_block.hip, lz_bands)
-  float* d_lz_w = nullptr;     // [2][8][kBlkLzTaps] interpolation weights of the local zoom
   int native_blk_fastw = 1;    // Gaussian weights without wrap-around logic where no alias of the filter spectrum matters
   int native_edge_merge = 1;   // tables for many records (cut 1): the split bands of a block share one edge item and its forward transforms
   int native_blk_long = 1;     // narrow Gaussian bands of the 1024-sample reach group in 8192-sample blocks (75 % of the outputs kept instead of 50 %)
@@ -424,6 +395,19 @@ namespace host {
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 enum class Kind { Linear, Circular, Stockwell };
+// Host sanitizer build (tests/sanitize: the library's host code on a stand-in HIP runtime under AddressSanitizer /
+// UBSan): every region a run carves out of the plan's scratch is reported here and checked -- inside the workspace, and
+// disjoint from every other live region (`shared`: the spectra a joint qi_cwt_stx tile's second run takes over from its
+// first).  The product build compiles these away.
+#ifdef QI_HOST_SANITIZE
+void layout_begin(const qi_plan* p, const char* run, bool keep_previous);
+void layout_note(const qi_plan* p, const char* what, const void* ptr, size_t bytes, bool shared = false);
+#define QI_LAYOUT_BEGIN(p, run, keep) ::qi::host::layout_begin(p, run, keep)
+#define QI_LAYOUT_NOTE(p, what, ptr, bytes, ...) ::qi::host::layout_note(p, what, ptr, bytes, ##__VA_ARGS__)
+#else
+#define QI_LAYOUT_BEGIN(p, run, keep) ((void)0)
+#define QI_LAYOUT_NOTE(p, what, ptr, bytes, ...) ((void)0)
+#endif
 // order of the zoom classes in a table's band list (classes 6, 5 and 0 share the coarsest grid)
 constexpr int kZoomListOrder[native::kZoomClasses] = {6, 5, 0, 1, 2, 3, 4};
 

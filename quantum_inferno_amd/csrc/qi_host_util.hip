@@ -88,3 +88,49 @@ std::mutex g_stft_mu;
 std::map<int, FftCache> g_stft_fft;  // per device
 
 }  // namespace qi
+
+#ifdef QI_HOST_SANITIZE
+// Host sanitizer build only (tests/sanitize): the regions a run carves out of the plan's scratch, checked as they are reported.
+namespace qi {
+namespace host {
+namespace {
+struct LayoutRegion {
+  const char* base;
+  size_t bytes;
+  std::string what;
+  int gen;
+};
+std::vector<LayoutRegion> g_regions;
+int g_layout_gen = 0;
+size_t g_layout_checked = 0;
+}  // namespace
+
+void layout_begin(const qi_plan* p, const char* run, bool keep_previous) {
+  (void)p;
+  (void)run;
+  if (!keep_previous) g_regions.clear();
+  ++g_layout_gen;
+}
+
+void layout_note(const qi_plan* p, const char* what, const void* ptr, size_t bytes, bool shared) {
+  const char* q = static_cast<const char*>(ptr);
+  ++g_layout_checked;
+  if (bytes == 0) return;
+  if (q < p->ws || q + bytes > p->ws + p->ws_bytes) {
+    fprintf(stderr, "layout: region '%s' [%td, +%zu) leaves the workspace of %zu bytes\n", what, q - p->ws, bytes, p->ws_bytes);
+    abort();
+  }
+  for (const auto& r : g_regions) {
+    const bool overlap = q < r.base + r.bytes && r.base < q + bytes;
+    if (!overlap) continue;
+    if (shared && r.gen != g_layout_gen && q == r.base && bytes <= r.bytes) continue;  // the spectra a joint tile shares
+    fprintf(stderr, "layout: region '%s' [%td, +%zu) overlaps '%s' [%td, +%zu)\n", what, q - p->ws, bytes, r.what.c_str(),
+            r.base - p->ws, r.bytes);
+    abort();
+  }
+  g_regions.push_back({q, bytes, what, g_layout_gen});
+}
+}  // namespace host
+}  // namespace qi
+extern "C" size_t qi_layout_regions_checked() { return qi::host::g_layout_checked; }
+#endif

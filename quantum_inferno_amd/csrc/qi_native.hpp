@@ -110,13 +110,6 @@ struct BlockBandT {
   // odd output samples), and for the Stockwell demodulation exp(-2 pi i idx / n) (one sample)
   R rot8_a[2], rot8_b[2];
   R rot1[2];
-  // narrow = 3, local zoom (BlockItem::wq = an lz code): the band's coarse samples -- every D-th output of the inverse
-  // transform -- are brought to baseband and the outputs are interpolated from them.  Gabor banks: kc = the baseband centre
-  // bin (a multiple of 16 next to kappa: the carrier exp(2 pi i kc u / 4096) of a thread's outputs u = u0 + 256 i does not
-  // depend on i), rot_lz = exp(2 pi i kc / 4096) (the odd sample of a pair).  Stockwell bands are demodulated on the coarse
-  // grid (shift, rot) and need neither.
-  int32_t kc;
-  R rot_lz[2];
   // nowrap = 1: every weight above 2^-30 of the peak belongs to a bin k in [0, kBlk) at distance k - kappa (no alias is
   // nearer), and amp > 0: weight(k) = exp2(la - (cw (k - kappa))^2), la = log2(amp) -- no wrap-around logic per weight
   int32_t nowrap;
@@ -125,12 +118,6 @@ struct BlockBandT {
 using BlockBand = BlockBandT<float>;
 
 constexpr int kBlkLongWq = 8;       // BlockItem::wq of a long block
-// Local zoom items: BlockItem::wq = wq + 16 log2(D) -- reach group wq, coarse grid of 4096 / D samples per block (D = 4:
-// filter spectra of <= 256 - 16 bins, groups of 4 bands; D = 8: <= 128 - 16 bins, groups of 8 bands)
-constexpr int kBlkLzTaps = 10;      // interpolator taps (bands oversampled >= 4 times on their coarse grid)
-constexpr int lz_code(int wq, int log2d) { return wq + 16 * log2d; }
-constexpr int lz_log2d(int code) { return code >> 4; }  // 0: not a local-zoom item
-constexpr int kBlkLzA = lz_code(2, 2), kBlkLzB = lz_code(4, 3);  // the two kinds the kernels are built for
 constexpr int kBlkLong = 2 * kBlk;  // record samples of a long block
 constexpr int kBlkLongValid = kBlkLong - 2048;  // outputs kept (taps within 1024 samples)
 struct BlockItem {  // one workgroup of the block launch
@@ -160,7 +147,6 @@ struct BlockArgs {
   const BlockItem* items;  // [nitems + nedge_items] device, most expensive first
   const BlockBandT<T>* bands;  // device, all reach groups
   const cplx<T>* bank;     // [rows][kBlk], scaled by 1 / kBlk
-  const float* lz_w;       // local zoom: [2][8][kBlkLzTaps] interpolation weights for D = 4 and D = 8 (lz_weights)
   // float64 Stockwell tables: demodulation factors from tables (see block_bands): per band of `bands` the sixteen
   // exp(-2 pi i idx 256 i / n), and exp(-2 pi i m / n) = demod_t1[m >> 10] demod_t2[m & 1023]
   const T* gauss_w;          // float64 tables: [bands][kBlk] the bands' real Gaussian filter weights (null: evaluated in registers)
@@ -355,7 +341,6 @@ int launch_z64_fine(const Z64FineArgs& a, int64_t n_channels, hipStream_t st);
 void z64_fine_weights(int cls, double* w /*[z64f_win(cls)][64]*/);
 
 void zoom_weights(int level, int lane_off, float* w /*[zoom_taps(level)][64]*/);
-void lz_weights(int log2d, float* w /*[1 << log2d][kBlkLzTaps]*/);
 
 template <typename T>
 int launch_time_reduce(const T* part, T* out, int64_t C, int64_t n, int nchunk, const T* edge_time, int64_t wmax,

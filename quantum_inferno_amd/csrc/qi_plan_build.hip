@@ -275,6 +275,35 @@ int upload_native_table(qi_plan* p, int kind, int64_t Lf, std::vector<native::Ba
 // Support analysis of `count` atom spectra starting at band j0 (rows built in `circular` or linear form).
 int analyse_support(qi_plan* p, int circular, int64_t L, int32_t B, int32_t j0, int32_t count, const double* d_par,
                     std::vector<double>* sup, hipStream_t st, double taper_e = 0.0) {
+#ifdef QI_HOST_SANITIZE
+  // Host sanitizer build (tests/sanitize): no kernel runs there, so the supports are the Gaussian atoms' own -- centre
+  // omega L / 2 pi, half-width where exp(-d^2 / 4 p_re) falls below the threshold -- with the whole row for an atom the
+  // record cuts off, and a taper's widening (~ 6.6 L / e bins at 2^-30, 13.2 at 2^-50, as the GPU analysis measures it).
+  // "Device" memory is host memory in that build: d_par is read directly.
+  (void)st;
+  (void)circular;
+  const double bits = p->d.dtype == QI_F64 ? 50.0 : 30.0;
+  sup->assign((size_t)count * 3, 0.0);
+  for (int32_t q = 0; q < count; ++q) {
+    const double p_re = d_par[j0 + q], om = d_par[2 * (int64_t)B + j0 + q];
+    const double kc = om * (double)L / (2.0 * M_PI), hw = std::sqrt(4.0 * p_re * bits * M_LN2) * (double)L / (2.0 * M_PI);
+    const bool cut = p_re * 0.25 * (double)p->n * (double)p->n <= bits * M_LN2;
+    double lo = 0.0, hi = (double)(L - 1);
+    if (!cut || taper_e > 0.0) {
+      const double extra = cut ? (p->d.dtype == QI_F64 ? 13.2 : 6.6) * (double)L / taper_e : 0.0;
+      lo = std::floor(kc - hw - extra);
+      hi = std::ceil(kc + hw + extra);
+      if (hi - lo + 1.0 >= (double)L) {
+        lo = 0.0;
+        hi = (double)(L - 1);
+      }
+    }
+    (*sup)[3 * (size_t)q] = 1.0;
+    (*sup)[3 * (size_t)q + 1] = lo;
+    (*sup)[3 * (size_t)q + 2] = hi;
+  }
+  return QI_OK;
+#endif
   const size_t row64 = (size_t)L * sizeof(double2);
   int64_t chunk = (int64_t)((p->ws_bytes - 4096) / row64);
   if (chunk < 1) {
@@ -375,39 +404,18 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
   bt.demod = demod;
   // reach groups: taps within 256, 512, 1024 samples (4096-sample blocks), and the long blocks (8192 samples) for the
   // narrow Gaussian bands of the 1024-sample group whose spectrum lies in the lower half of the 8192-bin grid
-  // ... and the local zoom items (narrow Gaussian bands of the 512- and 1024-sample groups at the decimated rate)
-  constexpr int NG = 6;
-  const int wqs[NG] = {1, 2, 4, native::kBlkLongWq, native::kBlkLzA, native::kBlkLzB};
-  // local zoom: the weights above 2^-30 of the peak within 4096 / (8 D) bins of the baseband centre (the band is then
-  // oversampled >= 4 times on the coarse grid); the centre is the band's own for a Stockwell band and the next multiple of
-  // 16 bins for a Gabor band (<= 8 bins off)
+  constexpr int NG = 4;
+  const int wqs[NG] = {1, 2, 4, native::kBlkLongWq};
   // (float64 tables: Gaussian weights in double from every bin -- the shortcuts below drop weights under 2^-30 of the peak)
   constexpr bool F64 = sizeof(T) == 8;
   const double drop_bits = F64 ? 52.0 : 30.0;
-  auto lz_kind = [&](const BlockPick& pk) -> int {
-    if (F64) return 0;
-    if (!p->native_blk_lz || !p->native_blk_analytic || !p->native_blk_narrow || !pk.analytic) return 0;
-    const double half = std::ceil(std::sqrt(30.0) / pk.cw);
-    if (2.0 * half + 2.0 > 256.0) return 0;
-    const double margin = demod ? 2.0 : 10.0;
-    if ((p->native_blk_lz & 1) && pk.wq == 2 && half + margin <= 128.0) return native::kBlkLzA;
-    if ((p->native_blk_lz & 2) && pk.wq == 4 && half + margin <= 64.0) return native::kBlkLzB;
-    return 0;
-  };
-  if (p->native_blk_lz && !p->d_lz_w) {
-    std::vector<float> wts(2 * 8 * native::kBlkLzTaps, 0.0f);
-    native::lz_weights(2, wts.data());
-    native::lz_weights(3, wts.data() + 8 * native::kBlkLzTaps);
-    QI_HIP(hipMalloc((void**)&p->d_lz_w, wts.size() * sizeof(float)));
-    QI_HIP(hipMemcpy(p->d_lz_w, wts.data(), wts.size() * sizeof(float), hipMemcpyHostToDevice));
-  }
   // first bin of the 256-bin window of a long band: centred on the band, kept inside the lower half of the 8192-bin grid
   // (the half a long block holds)
   auto long_window = [&](const BlockPick& pk) {
     return std::min<int64_t>(std::max<int64_t>((int64_t)std::llround(2.0 * pk.kappa) - 128, 0), native::kBlk - 256);
   };
   auto long_ok = [&](const BlockPick& pk, int cut) {
-    if (F64 || lz_kind(pk)) return false;
+    if (F64) return false;
     if (cut == 0) return false;  // few records: the long blocks' own launch would cost more than the blocks save
     if (!p->native_blk_long || !p->native_blk_analytic || !p->native_blk_narrow || pk.wq != 4 || !pk.analytic) return false;
     if (p->n < 4 * native::kBlkLong) return false;
@@ -430,8 +438,7 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
       const int32_t first = (int32_t)list.size();
       for (int32_t r = 0; r < rows; ++r) {
         const bool is_long = long_ok(picks[r], v);
-        const int lz = lz_kind(picks[r]);
-        const int home = lz ? lz : (is_long ? native::kBlkLongWq : picks[r].wq);  // the group that takes this band
+        const int home = is_long ? native::kBlkLongWq : picks[r].wq;  // the group that takes this band
         if (home != wqs[g]) continue;
         native::BlockBandT<T> b;
         memset(&b, 0, sizeof(b));
@@ -471,16 +478,6 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
           b.nowrap = 1;
           b.la = (T)std::log2(picks[r].amp / grid);
         }
-        if (lz) {
-          if (b.narrow != 1) {
-            set_error("block engine: a local-zoom band without a 256-bin window");
-            return QI_ERR_STATE;
-          }
-          b.narrow = 3;
-          b.kc = (int32_t)(((16 * (int64_t)std::llround(kappa / 16.0)) % native::kBlk + native::kBlk) % native::kBlk);
-          b.rot_lz[0] = (T)std::cos(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
-          b.rot_lz[1] = (T)std::sin(2.0 * M_PI * (double)b.kc / (double)native::kBlk);
-        }
         for (int k = 0; k < 4; ++k) {
           // r^(2^k), r = exp(-2 pi i idx 256 / n), from the exact integer phase
           const int64_t m = (int64_t)(((__int128)picks[r].shift * 256 * (1 << k)) % p->n);
@@ -506,15 +503,13 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
     for (int g = 0; g < NG; ++g) {
       const int32_t first = group_first[g], count = group_count[g];
       if (count == 0) continue;
-      // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block); a
-      // local-zoom workgroup takes its bands D at a time (one run of the LDS passes per D bands)
-      int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
-      if (const int l2d = native::lz_log2d(wqs[g])) per_wg = v == 0 ? (1 << l2d) : (l2d == 2 ? 12 : 8);
+      // the group's bands are dealt to `nchunk` workgroups per block (each pays one forward transform of the block)
+      const int per_wg = v == 0 ? p->native_blk_bands : p->native_blk_bands_batch;
       const int32_t nchunk = (int32_t)ceil_div(count, per_wg);
       const int64_t nblocks = ceil_div(p->n, native::block_valid(wqs[g]));
       if (tune_env("QI_NATIVE_VERBOSE"))
         fprintf(stderr, "[qi plan] block table %d cut %d, reach <= %d%s: %d bands (%d analytic, %d narrow, %d half) in %d workgroups x %lld blocks\n", kind, v,
-                g == 3 ? 1024 : 256 * (wqs[g] & 15), g == 3 ? " (8192-sample blocks)" : (g > 3 ? " (local zoom)" : ""), count,
+                g == 3 ? 1024 : 256 * (wqs[g] & 15), g == 3 ? " (8192-sample blocks)" : "", count,
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.analytic != 0; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.narrow == 1; }),
                 (int)std::count_if(list.begin() + first, list.begin() + first + count, [](const native::BlockBandT<T>& b) { return b.narrow == 2; }),
@@ -1029,7 +1024,13 @@ int build_stx_tables(qi_plan* p, int32_t B, const int64_t* shift_index, const do
           ++cnt;
           lo = d.out_band < lo ? d.out_band : lo;
         }
-      if (cnt > 0 && cnt <= 4 && lo == B - cnt && cnt < B) {
+      // (the pass tiles the plan's scratch like the hipFFT engine: one record's spectrum, `cnt` rows and the partial sums
+      // of the whole table must fit -- else the whole table goes to the hipFFT engine, which tiles over bands)
+      const size_t row = (size_t)p->n * (p->d.dtype == QI_F64 ? sizeof(double2) : sizeof(float2));
+      const int64_t nblk_e = ceil_div(p->n, kEpiSpan);
+      const size_t part = align_up((size_t)B * nblk_e * 8) + align_up((size_t)B * nblk_e * 24);
+      const bool left_fits = p->ws_bytes >= part + 2048 + row * (size_t)(cnt + 1);
+      if (cnt > 0 && cnt <= 4 && lo == B - cnt && cnt < B && left_fits) {
         bands.erase(std::remove_if(bands.begin(), bands.end(), [](const native::BandDesc& d) { return d.mode == 1; }), bands.end());
         p->stx_left_lo = lo;
         p->stx_left_n = cnt;

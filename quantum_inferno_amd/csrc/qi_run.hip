@@ -84,6 +84,11 @@ int run_transform(qi_plan* p, Kind kind, const void* sig_v, int64_t C, const qi_
   cplx<T>* Y = reinterpret_cast<cplx<T>*>(p->ws + tl.off_y);
   double* part_band = reinterpret_cast<double*>(p->ws + tl.off_pb);
   double* part_stat = reinterpret_cast<double*>(p->ws + tl.off_ps);
+  QI_LAYOUT_BEGIN(p, "hipFFT-engine tile", false);
+  QI_LAYOUT_NOTE(p, "X", X, (size_t)tl.Ct * L * sizeof(cplx<T>));
+  QI_LAYOUT_NOTE(p, "Y", Y, (size_t)tl.Ct * tl.Bt * L * sizeof(cplx<T>));
+  QI_LAYOUT_NOTE(p, "part_band", part_band, (size_t)tl.Ct * B * tl.nblk * 8);
+  QI_LAYOUT_NOTE(p, "part_stat", part_stat, (size_t)tl.Ct * B * tl.nblk * 24);
   const bool want_band = out->power_band != nullptr;
   const bool want_stat = out->stats != nullptr;
 
@@ -180,13 +185,23 @@ int run_stx_leftover(qi_plan* p, const void* sig_v, int64_t C, const qi_tfr_out*
   cplx<T>* Y = reinterpret_cast<cplx<T>*>(p->ws + tl.off_y);
   double* part_band = reinterpret_cast<double*>(p->ws + tl.off_pb);
   double* part_stat = reinterpret_cast<double*>(p->ws + tl.off_ps);
+  QI_LAYOUT_BEGIN(p, "hipFFT-engine tile", false);
+  QI_LAYOUT_NOTE(p, "X", X, (size_t)tl.Ct * n * sizeof(cplx<T>));
+  QI_LAYOUT_NOTE(p, "Y", Y, (size_t)tl.Ct * tl.Bt * n * sizeof(cplx<T>));
+  QI_LAYOUT_NOTE(p, "part_band", part_band, (size_t)tl.Ct * B * tl.nblk * 8);
+  QI_LAYOUT_NOTE(p, "part_stat", part_stat, (size_t)tl.Ct * B * tl.nblk * 24);
   const bool want_band = out->power_band != nullptr, want_stat = out->stats != nullptr;
   for (int64_t c0 = 0; c0 < C; c0 += tl.Ct) {
     const int64_t ct = (C - c0 < tl.Ct) ? C - c0 : tl.Ct;
+    p->prof.begin(st, QI_STAGE_MULTIPLY);
     QI_TRY(launch_pack_pad<T>(sig + c0 * n, X, ct, n, n, st));
     QI_TRY(fft_c2c<T>(p->fft, X, n, ct, HIPFFT_FORWARD, st));
     QI_TRY(launch_stx_window<T>(X, Y, ct, bt, n, p->d_stx_idx + j0, p->d_stx_coef + j0, st));
+    p->prof.end(QI_STAGE_MULTIPLY, st);
+    p->prof.begin(st, QI_STAGE_INVERSE);
     QI_TRY(fft_c2c<T>(p->fft, Y, n, ct * bt, HIPFFT_BACKWARD, st));
+    p->prof.end(QI_STAGE_INVERSE, st);
+    p->prof.begin(st, QI_STAGE_EPILOGUE);
     EpiArgs<T> a{};
     a.Y = Y;
     a.L = n;
@@ -213,6 +228,7 @@ int run_stx_leftover(qi_plan* p, const void* sig_v, int64_t C, const qi_tfr_out*
                                                      tl.nblk);
       QI_HIP(hipGetLastError());
     }
+    p->prof.end(QI_STAGE_EPILOGUE, st);
   }
   return QI_OK;
 }
@@ -490,11 +506,10 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     return QI_ERR_STATE;
   }
   const bool tail_one = time_via_part && (want_band || want_stat) && p->native_tail;
-  const bool overlap = blocks && p->native_overlap && nsplit == 0;  // (edge items need the zoom launch's output)
   // qi_cwt_stx: a CWT run whose records fit one tile leaves its block launch and tail to the Stockwell run ...
-  const bool deferring = defer && kind == 0 && Ct == C && blocks && !overlap && !shorts && tail_one;
+  const bool deferring = defer && kind == 0 && Ct == C && blocks && !shorts && tail_one;
   // ... which keeps the CWT run's scratch intact (its own follows it; only the spectra are shared) and finishes both
-  bool finishing = finish && finish->active && kind == 2 && share && blocks && !overlap && tail_one;
+  bool finishing = finish && finish->active && kind == 2 && share && blocks && tail_one;
   if (finishing) {
     const size_t need = align_up(e_x * (size_t)C) + align_up(finish->ws_used) + (per_chan - e_x) * (size_t)C + 64 * 256;
     if (need > p->ws_bytes) finishing = false;
@@ -508,9 +523,13 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
     p->shared_valid = false;  // the scratch is about to be overwritten
   }
   char* w = p->ws;
+  QI_LAYOUT_BEGIN(p, kind == 0 ? "run_native styx" : (kind == 1 ? "run_native atoms" : "run_native stx"), finishing);
+  bool carving_shared = share;  // (the first region: spectra the CWT run of a joint tile left behind)
   auto carve = [&](size_t bytes) {
     char* r = w;
     w += align_up(bytes * Ct);
+    QI_LAYOUT_NOTE(p, "native scratch", r, bytes * Ct, carving_shared);
+    carving_shared = false;
     return r;
   };
   cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));
@@ -528,32 +547,14 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   cplx<T>* zcoarse = e_zc ? reinterpret_cast<cplx<T>*>(carve(e_zc)) : nullptr;
   cplx<T>* zadd = e_add ? reinterpret_cast<cplx<T>*>(carve(e_add)) : nullptr;
 
-  if (overlap && !p->side) {
-    QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-  }
   for (int64_t c0 = 0; c0 < C; c0 += Ct) {
     const int64_t ct = (C - c0 < Ct) ? C - c0 : Ct;
-    // qi_cwt_stx, joint block launch: its band items need nothing but the records, so they run on a side stream BESIDE
-    // the zoom engine's launches (neither kernel fills the vector pipes by itself: ~47 % issue each); the edge items of the
-    // split bands follow the interpolation launch, whose output they add to
+    // qi_cwt_stx, joint block launch: the styx and the Stockwell bands of a block from one forward transform; the edge items
+    // of the split bands ride at its end (they add to the interpolation launch's output, which has run by then)
     const bool joint_blk = finishing && blocks && p->native_fuse > 1 && finish->ct == ct && !finish->demod && bt.demod &&
                            (finish->blk.coef != nullptr) == (out->coef != nullptr) &&
                            (finish->blk.bits != nullptr) == (out->bits != nullptr);
-    const bool pair = joint_blk && (p->native_pair || p->capturing) && !overlap;
-    // (native_pair >= 3: the fork as early as in a captured call; 4: the side stream at the lowest priority, so that the
-    // small launches of the other branch get the workgroup slots the block launch frees)
-    const bool early = p->capturing || p->native_pair >= 3;
-    if ((pair || (early && deferring)) && !p->side) {
-      int least = 0, greatest = 0;
-      if (p->native_pair >= 4) QI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      QI_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, p->native_pair == 5 ? greatest : least));
-      QI_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-      QI_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    }
-    if (early && !p->ev_parts) QI_HIP(hipEventCreateWithFlags(&p->ev_parts, hipEventDisableTiming));
-    auto launch_blocks = [&](hipStream_t bs, int phase = 0) -> int {  // phase 1: band items only, 2: edge items only (joint launch)
+    auto launch_blocks = [&](hipStream_t bs) -> int {
       native::BlockArgs<T> b{};
       b.n = n;
       b.nitems = il.nitems;
@@ -568,7 +569,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       b.items = il.d_items;
       b.bands = static_cast<const native::BlockBandT<T>*>(il.d_bands);
       b.bank = static_cast<const cplx<T>*>(bt.bank);
-      b.lz_w = p->d_lz_w;
       b.sig = sig + c0 * n;
       b.coef = out->coef ? static_cast<cplx<T>*>(out->coef) + c0 * B * n : nullptr;
       b.bits = out->bits ? static_cast<T*>(out->bits) + c0 * B * n : nullptr;
@@ -595,16 +595,8 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       p->prof.begin(bs, QI_STAGE_BLOCK);
       if (joint_blk) {
         QI_TRY(build_dual_items(p, cut));
-        const int32_t n_edge = p->blk[0].var[cut].nedge_items;
-        const native::DualItem* items = p->d_dual[cut];
-        int32_t count = p->n_dual[cut], nlong = p->n_dual_long[cut];
-        if (phase == 1) count -= n_edge;
-        if (phase == 2) {
-          items += count - n_edge;
-          count = n_edge;
-          nlong = 0;
-        }
-        QI_TRY(native::launch_block_dual<T>(finish->blk, b, items, count, nlong, phase == 1 ? 0 : n_edge, ct, bs));
+        QI_TRY(native::launch_block_dual<T>(finish->blk, b, p->d_dual[cut], p->n_dual[cut], p->n_dual_long[cut],
+                                            p->blk[0].var[cut].nedge_items, ct, bs));
       } else {
         if (finishing) QI_TRY(native::launch_block<T>(finish->blk, finish->demod, finish->ct, bs));
         QI_TRY(native::launch_block<T>(b, bt.demod, ct, bs));
@@ -613,35 +605,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       p->prof.unchain_span();
       return QI_OK;
     };
-    // A captured qi_cwt_stx call (QI_PLAN_GRAPH): the joint block launch is a branch of the graph that starts behind the
-    // clearing of BOTH tables' partial sums and nothing else -- the fork is recorded in the first (styx) run behind its
-    // clearing; the second run clears its partials on the side stream in front of the block launch and lets its own stream
-    // wait for just that.
-    const bool cap_pair = pair && early;
-    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, cap_pair ? p->side : st));
-    if (early && deferring && c0 == 0) {
-      QI_HIP(hipEventRecord(p->ev_fork, st));
-      QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-    }
-    if (pair) {
-      if (cap_pair) {
-        if (clear_parts) {
-          QI_HIP(hipEventRecord(p->ev_parts, p->side));
-          QI_HIP(hipStreamWaitEvent(st, p->ev_parts, 0));
-        }
-      } else {
-        QI_HIP(hipEventRecord(p->ev_fork, st));
-        QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-      }
-      QI_TRY(launch_blocks(p->side, 1));
-      QI_HIP(hipEventRecord(p->ev_join, p->side));
-    }
-    if (overlap) {  // fork: the block launch follows the clearing of the partials and nothing else
-      QI_HIP(hipEventRecord(p->ev_fork, st));
-      QI_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-      QI_TRY(launch_blocks(p->side));
-      QI_HIP(hipEventRecord(p->ev_join, p->side));
-    }
+    if (clear_parts) QI_HIP(hipMemsetAsync(parts0, 0, parts_bytes, st));
     p->prof.begin(st, QI_STAGE_FORWARD);
     if (share) {
       // X already holds the zero-padded spectra of these records
@@ -783,9 +747,6 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
           QI_TRY(native::launch_zoom_coarse<T>(z, zt.zoom_max_level, ct, st));
         }
         p->prof.end(QI_STAGE_ZOOM_COARSE, st);
-        if (pair && p->native_pair == 2) {  // the block launch has covered the coarse stage; the interpolation launch runs alone
-          QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-        }
         p->prof.begin(st, QI_STAGE_ZOOM);
         const bool joint_fine = joint && p->native_fuse > 3 && (finish->zoom.coef != nullptr) == (z.coef != nullptr) &&
                                 (finish->zoom.bits != nullptr) == (z.bits != nullptr);
@@ -804,13 +765,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       finish->has_zoom = false;
     }
     // (the edge items of the block launch finish the split bands the zoom launch began: it comes after it)
-    if (pair) {
-      QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-      if (p->blk[0].var[cut].nedge_items > 0) QI_TRY(launch_blocks(st, 2));
-    } else if (blocks && !overlap) {
-      QI_TRY(launch_blocks(st));
-    }
-    if (overlap) QI_HIP(hipStreamWaitEvent(st, p->ev_join, 0));  // join before the reductions are finalised
+    if (blocks) QI_TRY(launch_blocks(st));
     p->prof.begin(st, QI_STAGE_EPILOGUE);
     if (shorts) {
       native::EdgeArgs<T> e{};
@@ -1002,9 +957,11 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
   if (Ct > C) Ct = C;
   p->shared_valid = false;
   char* w = p->ws;
+  QI_LAYOUT_BEGIN(p, kind == 2 ? "run_native64 stx" : "run_native64 gabor", false);
   auto carve = [&](size_t bytes) {
     char* r = w;
     w += align_up(bytes * Ct);
+    QI_LAYOUT_NOTE(p, "native64 scratch", r, bytes * Ct);
     return r;
   };
   cplx<T>* X = reinterpret_cast<cplx<T>*>(carve(e_x));

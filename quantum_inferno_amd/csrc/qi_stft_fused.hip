@@ -374,187 +374,6 @@ __global__ void QI_STFT_BOUNDS k_stft_fused(const T* __restrict__ sig, const T* 
   }
 }
 
-// The product's transform split by the parity of the output bin (round 4).  A workgroup of k_stft_fused holds G whole
-// spectra (nfft / 2 complex numbers per segment: 8 at nfft = 2048 and two workgroups per CU) and so writes 8 coefficients =
-// 64 bytes of a frequency row, 32 bytes of a bits row: the store path is bound by the NUMBER of row pieces.  Here a workgroup
-// takes 16 segments and ONE half of their bins, nfft / 4 = MQ complex numbers per segment, from one MQ-point complex
-// transform:
-//   phase 0, even bins X[2 q], q = 0..MQ: the spectrum of the real sequence y[n] = v[n] + v[n + nfft / 2] of nfft / 2
-//            samples (v: the windowed, mean-free segment), packed as z[m] = y[2 m] + i y[2 m + 1] and untangled as before;
-//   phase 1, odd bins: U = FFT_MQ(u), u[n] = ((v[n] - v[n + 2 MQ]) - i (v[n + MQ] - v[n + 3 MQ])) exp(-2 pi i n / nfft) is
-//            U[j] = X[4 j + 1], and X[4 j + 3] = conj X[nfft - 4 j - 3] = conj U[MQ - 1 - j] for a real segment.
-// Same arithmetic per bin, half the LDS per segment, runs of 16 (128 B / 64 B), every segment loaded by two workgroups
-// (the second one hits L2).  Items (record, phase, group) are dealt to the XCDs in contiguous ranges as above.
-template <typename T, int LOG2R, int LOG2C>
-__global__ void __launch_bounds__(kStftThreads) k_stft_split(const T* __restrict__ sig, const T* __restrict__ win,
-                                                             const cplx<T>* __restrict__ twg, cplx<T>* __restrict__ Z,
-                                                             T* __restrict__ bits, StftFusedArgs a) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  constexpr int R = 1 << LOG2R, C = 1 << LOG2C, MQ = R * C, RS = C + 1, TILE = R * RS + 1, G = 16, LG = 4;
-  constexpr int NTAB = 2 * MQ;  // the table holds exp(-i pi k / NTAB) = exp(-2 pi i k / nfft), k = 0..NTAB
-  cplx<T>* __restrict__ data = reinterpret_cast<cplx<T>*>(lds_raw);
-  cplx<T>* __restrict__ tw = data + (size_t)G * TILE;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  const int64_t item = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= a.per_xcd || item >= a.nitems) return;
-  const int64_t c = item / (2 * a.ngroups);
-  const int rem = (int)(item % (2 * a.ngroups)), phase = rem / a.ngroups;
-  const int64_t m0 = (int64_t)(rem % a.ngroups) * G;
-  const T* __restrict__ x = sig + c * a.n;
-
-  constexpr int NT = (NTAB + kStftThreads) / kStftThreads;
-  cplx<T> twv[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int k = tid + i * kStftThreads;
-    twv[i] = k <= NTAB ? twg[k] : mk<T>(T(0), T(0));
-  }
-  // segments: one wave per segment; lane l holds the sample pairs j = q MQ / 2 + l + 64 t of the four quarters q
-  constexpr int NW = kStftThreads / kWave, NQ = MQ / 2 / kWave;
-  static_assert(NQ >= 1, "k_stft_split: transform lengths from 512 samples");
-  for (int g = wv; g < G; g += NW) {
-    const int64_t m = m0 + g;
-    cplx<T>* __restrict__ d = data + (size_t)g * TILE;
-    if (m >= a.nseg) {  // past the last segment: zeros (never stored)
-      for (int e = lane; e < MQ; e += kWave) d[(e >> LOG2C) * RS + (e & (C - 1))] = mk<T>(T(0), T(0));
-      continue;
-    }
-    const int64_t base = m * a.hop - a.lead;
-    cplx<T> h[4][NQ], w[4][NQ];
-    const bool whole = a.seg == 4 * MQ && base >= 0 && base + 4 * MQ <= a.n &&
-                       ((reinterpret_cast<uintptr_t>(x + base) | reinterpret_cast<uintptr_t>(win)) & (2 * sizeof(T) - 1)) == 0;
-    if (whole) {
-      const cplx<T>* __restrict__ xp = reinterpret_cast<const cplx<T>*>(x + base);
-      const cplx<T>* __restrict__ wp = reinterpret_cast<const cplx<T>*>(win);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) h[q][t] = xp[q * (MQ / 2) + lane + kWave * t];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) w[q][t] = wp[q * (MQ / 2) + lane + kWave * t];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-          const int64_t i0 = 2 * (int64_t)(q * (MQ / 2) + lane + kWave * t), k0 = base + i0;
-          h[q][t] = mk<T>(i0 < a.seg ? stft_sample<T>(x, a.n, k0, 0) : T(0), i0 + 1 < a.seg ? stft_sample<T>(x, a.n, k0 + 1, 0) : T(0));
-          w[q][t] = mk<T>(i0 < a.seg ? win[i0] : T(0), i0 + 1 < a.seg ? win[i0 + 1] : T(0));
-        }
-    }
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) acc += (double)h[q][t].x + (double)h[q][t].y;
-    acc = wave_sum(acc);
-    const T mean = a.detrend ? (T)(acc / (double)a.seg) : T(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) h[q][t] = mk<T>((h[q][t].x - mean) * w[q][t].x, (h[q][t].y - mean) * w[q][t].y);
-    if (phase == 0) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-          const int e = q * (MQ / 2) + lane + kWave * t;
-          d[(e >> LOG2C) * RS + (e & (C - 1))] = mk<T>(h[q][t].x + h[q + 2][t].x, h[q][t].y + h[q + 2][t].y);
-        }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-        const int e = 2 * (lane + kWave * t);  // the samples n = e, e + 1 of the first quarter
-        const cplx<T> t0 = twg[e], t1 = twg[e + 1];
-        const cplx<T> u0 = cmul(mk<T>(h[0][t].x - h[2][t].x, h[3][t].x - h[1][t].x), t0);
-        const cplx<T> u1 = cmul(mk<T>(h[0][t].y - h[2][t].y, h[3][t].y - h[1][t].y), t1);
-        cplx<T>* __restrict__ at = d + (e >> LOG2C) * RS + (e & (C - 1));
-        at[0] = u0;
-        at[1] = u1;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int k = tid + i * kStftThreads;
-    if (k <= NTAB) tw[k] = twv[i];
-  }
-  __syncthreads();
-
-  // step 1: columns (R-point transforms, times W_MQ^(c k1) = table entry 4 c k1 of a period of 4 MQ)
-  for (int q = tid; q < G * C; q += kStftThreads) {
-    const int g = q >> LOG2C, cc = q & (C - 1);
-    cplx<T>* __restrict__ d = data + (size_t)g * TILE + cc;
-    cplx<T> v[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = d[r * RS];
-    native::fft_reg<T, R, -1>(v);
-#pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) {
-      cplx<T> y = v[native::brev(k1, LOG2R)];
-      if (k1 > 0) {
-        const int j4 = 4 * cc * k1;
-        const cplx<T> wq = tw[j4 & (NTAB - 1)];
-        y = cmul(y, (j4 & NTAB) ? mk<T>(-wq.x, -wq.y) : wq);
-      }
-      d[k1 * RS] = y;
-    }
-  }
-  __syncthreads();
-  // step 2: rows
-  for (int q = tid; q < G * R; q += kStftThreads) {
-    const int g = q >> LOG2R, k1 = q & (R - 1);
-    cplx<T>* __restrict__ d = data + (size_t)g * TILE + k1 * RS;
-    cplx<T> v[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) v[j] = d[j];
-    native::fft_reg<T, C, -1>(v);
-#pragma unroll
-    for (int k2 = 0; k2 < C; ++k2) d[k2] = v[native::brev(k2, LOG2C)];
-  }
-  __syncthreads();
-
-  // store: thread = (bin slot of a sweep of 16, segment g); Z[k] = row k mod R, column k / R
-  const int g = tid & (G - 1), S = kStftThreads >> LG;
-  const int64_t m = m0 + g;
-  if (m >= a.nseg) return;
-  const cplx<T>* __restrict__ d = data + (size_t)g * TILE;
-  const int nf = 2 * MQ + 1;
-  const T scale = (T)a.scale, eps = (T)a.eps;
-  const int64_t rec = c * nf * a.nseg + m;
-  if (phase == 0) {
-    const T hs = T(0.5) * scale;
-    for (int q = tid >> LG; q <= MQ / 2; q += S) {
-      const int ka = q, kb = (MQ - q) & (MQ - 1);
-      const cplx<T> za = d[(ka & (R - 1)) * RS + (ka >> LOG2R)], zb = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
-      const cplx<T> wq = tw[2 * q];
-      const T A = za.x + zb.x, B = za.y - zb.y;
-      const cplx<T> wo = cmul(mk<T>(za.x - zb.x, za.y + zb.y), wq);
-      const cplx<T> X = mk<T>(hs * (A + wo.y), hs * (B - wo.x)), Y = mk<T>(hs * (A - wo.y), hs * (-B - wo.x));
-      const int64_t ra = rec + (int64_t)(2 * q) * a.nseg, rb = rec + (int64_t)(2 * (MQ - q)) * a.nseg;
-      Z[ra] = X;
-      bits[ra] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
-      if (2 * q != MQ) {
-        Z[rb] = Y;
-        bits[rb] = log2_t(sqrt_t(Y.x * Y.x + Y.y * Y.y) + eps);
-      }
-    }
-  } else {
-    for (int j = tid >> LG; j < MQ / 2; j += S) {
-      const int kb = MQ - 1 - j;
-      const cplx<T> ua = d[(j & (R - 1)) * RS + (j >> LOG2R)], ub = d[(kb & (R - 1)) * RS + (kb >> LOG2R)];
-      const cplx<T> X = mk<T>(scale * ua.x, scale * ua.y), Y = mk<T>(scale * ub.x, -scale * ub.y);
-      const int64_t ra = rec + (int64_t)(4 * j + 1) * a.nseg, rb = rec + (int64_t)(4 * j + 3) * a.nseg;
-      Z[ra] = X;
-      bits[ra] = log2_t(sqrt_t(X.x * X.x + X.y * X.y) + eps);
-      Z[rb] = Y;
-      bits[rb] = log2_t(sqrt_t(Y.x * Y.x + Y.y * Y.y) + eps);
-    }
-  }
-}
-
 // Inverse of the ShortTimeFFT-convention transform (qi_sliding_istft; ref utilities/short_time_fft.py:106-137, scipy's
 // ShortTimeFFT.istft) in ONE kernel instead of un-transpose -> batched C2R FFT -> overlap-add (round 4).  A workgroup owns
 // GOWN consecutive hops of the output and holds the GOWN + H slices that cover them (H = ceil(seg / hop) - 1 slices of the
@@ -772,26 +591,6 @@ static int launch_stft_shape(const T* sig, const T* win, cplx<T>* Z, T* bits, in
   QI_TRY(stft_twiddles<T>(M, &twg));
   // the product's own call (styx_fft: zeros beyond the record, both panels, log2 bits) runs the specialised loops
   const bool plain = Z && bits && !a.welch_part && a.pad_mode == 0 && a.real_kind == 0 && a.roll == 0;
-  if constexpr (sizeof(T) == 4 && LR + LC >= 8 && LR + LC <= 10) {  // nfft = 512, 1024, 2048: split by bin parity (k_stft_split)
-    // (measured: 0.447-0.450 ms against k_stft_fused's 0.381-0.386 at configs[2] -- a development switch, off by default)
-    const char* split_env = tune_env("QI_STFT_SPLIT");
-    if (plain && split_env && atoi(split_env) == 1) {
-      constexpr int LQ = LR + LC - 1, QR = LQ / 2, QC = LQ - QR;  // MQ = M / 2 = 2^QR x 2^QC
-      const size_t qtile = ((size_t)1 << QR) * (((size_t)1 << QC) + 1) + 1;
-      const size_t qlds = (16 * qtile + M + 1) * sizeof(cplx<T>);
-      const void* qfn = reinterpret_cast<const void*>(&k_stft_split<T, QR, QC>);
-      QI_TRY(allow_dynamic_lds(qfn, qlds));
-      a.G = 16;
-      a.log2g = 4;
-      a.ngroups = (int32_t)ceil_div(nseg, 16);
-      g_last_ngroups = a.ngroups;
-      a.nitems = 2 * (int64_t)a.ngroups * C;
-      a.per_xcd = (int32_t)ceil_div(a.nitems, 8);
-      k_stft_split<T, QR, QC><<<dim3((unsigned)(8 * a.per_xcd)), kStftThreads, qlds, st>>>(sig, win, twg, Z, bits, a);
-      QI_LAUNCH_CHECK();
-      return QI_OK;
-    }
-  }
   const void* fn = plain ? reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC, true>)
                          : reinterpret_cast<const void*>(&k_stft_fused<T, LR, LC, false>);
   QI_TRY(allow_dynamic_lds(fn, lds));

@@ -413,17 +413,5 @@ void zoom_weights(int cls, int lane_off, float* w) {
   }
 }
 
-// Local zoom of the block engine (qi_block.hip): 10 taps per output phase p = 0 .. D - 1 (x = p / D), bands oversampled
-// >= 4 times on their coarse grid; w[p][c] multiplies coarse sample q - 4 + c, q = floor(u / D)
-void lz_weights(int log2d, float* w) {
-  const int D = 1 << log2d;
-  const long double band = 3.14159265358979323846264338327950288L / 4.0L;
-  for (int p = 0; p < D; ++p) {
-    long double t[10];
-    interp_taps(kBlkLzTaps, band, (long double)p / (long double)D, t);
-    for (int c = 0; c < kBlkLzTaps; ++c) w[p * kBlkLzTaps + c] = (float)t[c];
-  }
-}
-
 }  // namespace native
 }  // namespace qi

@@ -140,7 +140,7 @@ def styx_bank_tables(order, n, fs, dictionary_type="norm"):
 class TfrPlan:
     """GPU plan for records of n samples."""
 
-    def __init__(self, n, dtype=torch.float32, device=None, workspace_bytes=None, engine=_lib.QI_ENGINE_AUTO, graph=False):
+    def __init__(self, n, dtype=torch.float32, device=None, workspace_bytes=None, engine=_lib.QI_ENGINE_AUTO):
         self._lib = _lib.require_gpu()
         self.n = int(n)
         self.rdtype = _real_dtype(dtype)
@@ -156,7 +156,7 @@ class TfrPlan:
             dtype=_lib.QI_F64 if self.rdtype == torch.float64 else _lib.QI_F32,
             device=self.device.index,
             engine=engine,
-            flags=_lib.QI_PLAN_GRAPH if graph else 0,
+            flags=0,
             workspace_bytes=self.workspace_bytes,
         )
         _lib.check(self._lib.qi_plan_create(C.byref(self._handle), C.byref(desc)))

@@ -4,11 +4,11 @@ same seeded inputs, (3) size-independent properties at the benchmark size.
 
 Stated tolerances (max|delta| relative to max|reference| of the panel unless noted):
   float64 path : 1e-11 coefficients, 1e-9 log2 bits, 1e-10 reductions.  A bits tolerance needs a magnitude
-                 floor (log2 of a coefficient far below the panel maximum amplifies ANY absolute error, the reference's own
-                 FFT rounding of ~2e-15 max included): 1e-5 max on the hipFFT engine (= the reference's algorithm: 1e-9 bits
-                 there is an absolute error of 7e-15 max), and on the native engines at 2^20 samples the floor the
-                 coefficient contract itself implies, 1e-11 / (1e-9 ln 2) = 1.5e-2 max (BITS_FLOOR_NATIVE64), with the
-                 round-4 check (1e-8 bits from 1e-3 max) kept beside it
+                 floor -- log2 of a coefficient far below the panel maximum amplifies ANY absolute error, the reference's
+                 own FFT rounding (~2e-15 max) and the 1.8e-12 amplitude rounding of its cwt_atoms path
+                 included.  1e-9 bits are asserted from the floor the coefficient contract itself implies,
+                 |z| >= 1e-11 / (1e-9 ln 2) = 1.5e-2 max (BITS_FLOOR64); beside it round 4's wider check stays: 1e-8 bits
+                 from 1e-6 max on the hipFFT engine (the reference's algorithm) and from 1e-3 max on the native engines
   float32 path : 2e-5 coefficients, 1e-3 log2 bits where |z| >= 1e-3 max, 1e-4 reductions; at the benchmark
                  length every band is also held to 1e-5 of ITS OWN maximum (weak bands included)
 Band tables, shift indices, STFT shapes / time / frequency axes: bit-exact.
@@ -27,9 +27,9 @@ from quantum_inferno_amd import cwt_atoms, engine, scales_dyadic, styx_cwt, styx
 
 pytestmark = pytest.mark.gpu
 
-TOL = {np.float64: dict(coef=1e-11, bits=1e-9, bits_floor=1e-5, red=1e-10),
+TOL = {np.float64: dict(coef=1e-11, bits=1e-9, bits_floor=1.5e-2, bits_wide=(1e-8, 1e-6), red=1e-10),
        np.float32: dict(coef=2e-5, bits=1e-3, bits_floor=1e-3, red=1e-4, row=1e-5)}
-BITS_FLOOR_NATIVE64 = 1.5e-2  # coef / (bits ln 2): where the 1e-11 coefficient contract implies 1e-9 bits
+BITS_FLOOR64 = 1.5e-2  # coef / (bits ln 2): where the 1e-11 coefficient contract implies 1e-9 bits
 # (measured at 2^20 samples against the reference, tools/measure_parity.py: panel-relative error < 1e-6, every band
 # within 2.4e-6 of its own maximum at orders 3 and 12, bits within 3e-4 above 1e-3 of the panel maximum)
 
@@ -45,6 +45,9 @@ def check_bits(bits, ref_coef, tol):
     sel = mag >= tol["bits_floor"] * mag.max()
     ref_bits = np.log2(mag + orc.EPS64)
     assert np.max(np.abs(bits - ref_bits)[sel]) <= tol["bits"]
+    if "bits_wide" in tol:  # a second, looser tolerance over a wider range of magnitudes
+        wide_tol, wide_floor = tol["bits_wide"]
+        assert np.max(np.abs(bits - ref_bits)[mag >= wide_floor * mag.max()]) <= wide_tol
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -127,43 +130,6 @@ def test_stft_benchmark_shape_vs_reference(golden, dtype):
     assert np.max(np.abs(z[:, cols] - g[f"z_cols_{dtype}"])) <= tol * zmax
     big = np.abs(g[f"z_cols_{dtype}"]) >= 1e-3 * zmax
     assert np.max(np.abs(bits[:, cols] - g[f"bits_cols_{dtype}"])[big]) <= (2e-3 if dtype == "float32" else 1e-9)
-
-
-def test_stft_split_kernel_vs_reference(golden):
-    """k_stft_split (the 2048-point transform split by bin parity, a development switch: QI_STFT_SPLIT=1) against the same
-    reference rows and columns as the product kernel, in a process of its own (the switches are read once per process)."""
-    import subprocess
-    import sys
-
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import tfr_oracle as orc
-from quantum_inferno_amd import styx_fft
-g = np.load(%r)
-n, fs, order = 1 << 20, 1000.0, 12
-sig = orc.synth_chirp(n, fs, dtype=np.float32)
-z, bits, t, f = styx_fft.stft_from_sig(sig, fs, order)
-rows, cols = g["rows_float32"], g["cols_float32"]
-zmax = float(g["zmax_float32"])
-e1 = float(np.max(np.abs(z[rows] - g["z_rows_float32"])) / zmax)
-e2 = float(np.max(np.abs(z[:, cols] - g["z_cols_float32"])) / zmax)
-big = np.abs(g["z_cols_float32"]) >= 1e-3 * zmax
-e3 = float(np.max(np.abs(bits[:, cols] - g["bits_cols_float32"])[big]))
-import hashlib
-print("SPLIT", z.shape[0], z.shape[1], e1, e2, e3, hashlib.sha1(np.ascontiguousarray(z).tobytes()).hexdigest())
-""" % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden", "stft_n1048576_o12.npz"))
-    env = dict(os.environ, QI_TUNE="1", QI_STFT_SPLIT="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("SPLIT")][-1].split()
-    assert (int(line[1]), int(line[2])) == (1025, 1025)
-    assert float(line[3]) <= 2e-6 and float(line[4]) <= 2e-6 and float(line[5]) <= 2e-3
-    # (the other kernel did run: its roundings differ from the product kernel's)
-    import hashlib
-
-    z0 = styx_fft.stft_from_sig(orc.synth_chirp(1 << 20, 1000.0, dtype=np.float32), 1000.0, 12)[0]
-    assert hashlib.sha1(np.ascontiguousarray(z0).tobytes()).hexdigest() != line[6]
 
 
 def test_stft_2d_batch_and_errors(golden):
@@ -631,8 +597,7 @@ def test_float64_native_engine_vs_oracle(golden, order):
         # (at 2^20 samples the float64 transforms carry ~1e-12 of the panel maximum: 1e-9 bits where the coefficient
         # tolerance implies them, and 1e-8 from 1e-3 of the maximum as in round 4)
         got_bits = a.bits[0][torch.tensor(pick, device="cuda")].cpu().numpy()
-        check_bits(got_bits, want, dict(bits=tol["bits"], bits_floor=BITS_FLOOR_NATIVE64))
-        check_bits(got_bits, want, dict(bits=1e-8, bits_floor=1e-3))
+        check_bits(got_bits, want, dict(bits=tol["bits"], bits_floor=BITS_FLOOR64, bits_wide=(1e-8, 1e-3)))
         b = getattr(ref, name)(xt, coef=True, reductions=True)
         worst = float((a.coef - b.coef).abs().amax(dim=2).max()) / scale
         assert worst <= tol["coef"], (name, order, worst)
@@ -651,7 +616,7 @@ def test_float64_native_engine_vs_oracle(golden, order):
         assert np.max(np.abs(x[:: n // 4096] - g64["sig_samples"])) == 0.0 and np.array_equal(f, g64["f_o3"])
         for name in ("cwt", "stx"):
             res = getattr(nat, name)(xt, coef=True, bits=True, reductions=True)
-            check_digest(res, g64, name, order, dict(tol, bits_floor=1e-3, row=5e-9, ent=5e-8), g64["rows_o3"])
+            check_digest(res, g64, name, order, dict(tol, bits_floor=1e-3, bits_wide=(1e-8, 1e-3), row=5e-9, ent=5e-8), g64["rows_o3"])
             del res
     g = golden("large_n1048576.npz" if order == 3 else "large_n1048576_o12.npz")
     x32 = torch.from_numpy(orc.synth_chirp(n, fs, dtype=np.float32).astype(np.float64)).cuda().unsqueeze(0)
@@ -765,7 +730,7 @@ def test_float64_order12_batches_at_timed_shape(golden, channels, fs, ws_cap):
         # H = log2 S - sum(P log2 P) / S has no such term)
         ent_tol = 1.05 * nb * n * float(orc.EPS64) / np.log(2.0) + 1e-9
         for a, name in zip(full, ("cwt", "stx")):
-            check_digest(a, g, name, order, dict(tol, bits_floor=1e-3, row=5e-9, ent=ent_tol), g["rows_o12"])
+            check_digest(a, g, name, order, dict(tol, bits_floor=1e-3, bits_wide=(1e-8, 1e-3), row=5e-9, ent=ent_tol), g["rows_o12"])
     del full, lean
     plan.close()
 
@@ -1062,38 +1027,25 @@ def test_staged_result_copy_is_bit_equal(monkeypatch):
         assert all(np.array_equal(r, ref) for r in out[key])
 
 
-def test_cwt_stx_graph_mode_is_bit_equal():
-    """QI_PLAN_GRAPH: qi_cwt_stx calls of one or two float32 records are captured once per set of buffers as a HIP graph (the
-    joint block launch a branch beside the forward / coarse / interpolation chain) and replayed: the same kernels on the
-    same data -- every output bit-equal to the eager launches, for replays, for a second set of buffers and after the records
-    change in place."""
-    n, fs, order = 1 << 18, 1000.0, 3
-    nb = len(scales_dyadic.log_frequency_hz_from_fft_points(fs, n, order))
-    for channels in (1, 2):
-        x = torch.from_numpy(np.stack([orc.synth_chirp(n, fs, c, channels, np.float32) for c in range(channels)])).cuda()
-        plans = []
-        for graph in (False, True):
-            plan = engine.TfrPlan(n, np.float32, None, engine.TfrPlan.workspace_for(n, nb, np.float32, channels), graph=graph)
-            plan.set_styx_bank(order, fs)
-            plan.set_stx_bands(order, fs)
-            plans.append(plan)
-        eager, graph = plans
-        ref = eager.cwt_stx(x, coef=True, reductions=True)
-        out_a = graph.cwt_stx(x, coef=True, reductions=True)       # call 1 with these buffers: eager inside the library
-        out_b = graph.cwt_stx(x, coef=True, reductions=True)       # another set of buffers
-        for k in range(4):                                           # call 2 captures, 3 and 4 replay
-            graph.cwt_stx(x, out=out_a)
-            graph.cwt_stx(x, out=out_b)
-            for got in (out_a, out_b):
-                for g, r in zip(got, ref):
-                    assert torch.equal(g.coef, r.coef) and torch.equal(g.reduced, r.reduced), (channels, k)
-        x.mul_(0.5)  # the records change in place: the replayed graph reads the new data
-        ref = eager.cwt_stx(x, coef=True, reductions=True)
-        graph.cwt_stx(x, out=out_a)
-        for g, r in zip(out_a, ref):
-            assert torch.equal(g.coef, r.coef) and torch.equal(g.reduced, r.reduced)
-        eager.close()
-        graph.close()
+def test_plan_desc_flags_are_reserved():
+    """qi_plan_desc.flags is reserved (round 4's experimental graph mode left the library): anything but 0 is refused, so a C
+    caller that leaves garbage in the field gets an error instead of a silent mode switch."""
+    import ctypes as C
+
+    from quantum_inferno_amd import _lib
+
+    lib = _lib.require_gpu()
+    handle = C.c_void_p()
+    for flags, ok in ((0, True), (1, False), (0x40000000, False)):
+        desc = _lib.PlanDesc(n=4096, dtype=_lib.QI_F32, device=torch.cuda.current_device(), engine=_lib.QI_ENGINE_AUTO, flags=flags,
+                             workspace_bytes=1 << 24)
+        rc = lib.qi_plan_create(C.byref(handle), C.byref(desc))
+        assert (rc == 0) == ok, (flags, rc)
+        if ok:
+            assert lib.qi_plan_destroy(handle) == 0
+        else:
+            with pytest.raises(_lib.QiError, match="reserved"):
+                _lib.check(rc)
 
 
 def test_plan_ring_matches_single_plan():
