@@ -67,7 +67,10 @@ int qi_plan_create(qi_plan** plan, const qi_plan_desc* desc) {
   if (const char* e = tune_env("QI_NATIVE_Z64_COARSE")) p->native_z64_coarse = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_Z64_BLOCK_FROM")) p->native_z64_block_from = atoi(e);
   if (const char* e = tune_env("QI_NATIVE_BLK64_WTAB")) p->native_blk64_wtab = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_BLK64_NARROW")) p->native_blk64_narrow = atoi(e);
+  if (const char* e = tune_env("QI_NATIVE_MIN_LOG2N")) p->native_min_log2n = atoi(e);
   if (desc->dtype == QI_F64) {  // the float32 zoom / block / split engines are sized for the float32 tolerance
+    if (!tune_env("QI_NATIVE_MIN_LOG2N")) p->native_min_log2n = 15;
     const int short64 = p->native_short && !(tune_env("QI_NATIVE_SHORT64") && atoi(tune_env("QI_NATIVE_SHORT64")) == 0);
     // (the block engine runs float64 tables in double arithmetic: analytic Gaussian bands, no narrow-spectrum shortcuts)
     const int block64 = p->native_block && !(tune_env("QI_NATIVE_BLOCK64") && atoi(tune_env("QI_NATIVE_BLOCK64")) == 0);

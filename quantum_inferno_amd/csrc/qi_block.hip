@@ -224,14 +224,20 @@ __device__ __forceinline__ void fft4096_tail(cplx<T> (&v)[16], cplx<T>* __restri
     cplx<T> t[16];
 #pragma unroll
     for (int q2 = 0; q2 < 16; ++q2) t[q2] = v[brev(q2, 4)];
-    const int pos = col ^ ((col >> 4) & 1);
+    // (16-byte elements -- double2 --: a ds_write_b128 is served in groups of EIGHT contiguous lanes over 32 banks, i.e. the
+    // eight columns 0, 2, ... 14 of a group must fall on eight different 16-byte slots modulo 128 bytes: the swap bit is bit 3
+    // of the column there, bit 4 for the 8-byte elements' groups of sixteen.  Round 4's counters had 35 % of k_block64's LDS
+    // cycles as bank conflicts, all of them this store's 2-way ones.)
+    constexpr int SW = sizeof(cplx<T>) == 16 ? 3 : 4;
+    const int pos = col ^ ((col >> SW) & 1);
 #pragma unroll
     for (int q2 = 0; q2 < 16; ++q2) buf[q2 * kBlkRow1 + pos] = t[q2];
   }
   __syncthreads();
   const int k0 = tid & 15, q2t = tid >> 4;
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) v[k1] = buf[q2t * kBlkRow1 + 16 * k1 + (k0 ^ (k1 & 1))];
+  for (int k1 = 0; k1 < 16; ++k1)  // column 16 k1 + k0 sits at the position the store's swap gave it
+    v[k1] = buf[q2t * kBlkRow1 + 16 * k1 + (sizeof(cplx<T>) == 16 ? (k0 ^ ((k0 >> 3) & 1)) : (k0 ^ (k1 & 1)))];
   fft_reg<T, 16, DIR>(v);  // over k1 -> q1
 #pragma unroll
   for (int q1 = 1; q1 < 16; ++q1) {
@@ -325,8 +331,8 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
     } else {
       if (jj + 1 < band_count) bd_next = load_uniform(a.bands + band_first + jj + 1);
     }
-    cplx<T> v[16];  // (F64: float64 tables hold analytic bands only, none of them `narrow`)
-    if (!EDGE && !F64 && bd.narrow == 1) {
+    cplx<T> v[16];  // (F64: float64 tables hold analytic bands only)
+    if (!EDGE && bd.narrow == 1) {
       // narrow filter spectrum (<= 256 bins from klo): this thread's only bin with a weight above 2^-30 of the peak is
       // k = klo + ((col - klo) mod 256); the first pass of the inverse transform is y om^q (sparse_head16)
       QI_BSTAMP(1);
@@ -335,15 +341,22 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
       const int k = (bd.klo + kres) & (kBlk - 1);
       const bool first = (k >> 8) == (bd.klo >> 8);
       const cplx<T> x = pick_pair16<T>(S, __builtin_amdgcn_readfirstlane(bd.klo >> 8), first);
-      T dk = (T)(k - bd.kappa_int) - (T)bd.kappa_frac;
-      T amp = (T)bd.amp;
-      if (dk > (T)(kBlk / 2)) {
-        dk -= (T)kBlk;
-        if (!DEMOD) amp = -amp;  // half-integer sample grid: the aliases alternate in sign
+      T r;
+      if constexpr (F64) {
+        // (float64: the plan-time weight table holds this bin's weight -- block_bands' formula in double, aliases and signs
+        // included; `narrow` is set there only when every weight above 2^-52 of the peak lies inside the 256-bin window)
+        r = a.gauss_w[(int64_t)(band_first + jj) * kBlk + k];
+      } else {
+        T dk = (T)(k - bd.kappa_int) - (T)bd.kappa_frac;
+        T amp = (T)bd.amp;
+        if (dk > (T)(kBlk / 2)) {
+          dk -= (T)kBlk;
+          if (!DEMOD) amp = -amp;  // half-integer sample grid: the aliases alternate in sign
+        }
+        if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
+        const T e = (T)bd.cw * dk;
+        r = amp * fast_exp2(-e * e);
       }
-      if (DEMOD && dk < -(T)(kBlk / 2)) dk += (T)kBlk;
-      const T e = (T)bd.cw * dk;
-      const T r = amp * fast_exp2(-e * e);
       cplx<T> wq = w;
       asm volatile("" : "+v"(wq.x), "+v"(wq.y));
       const cplx<T> om = cmul(wq, first ? mk<T>((T)bd.rot_a[0], (T)bd.rot_a[1]) : mk<T>((T)bd.rot_b[0], (T)bd.rot_b[1]));
@@ -435,7 +448,7 @@ __device__ __forceinline__ void block_bands(const BlockArgs<T>& a, int32_t blk_i
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = cmul(S[b], h[b]);
     }
-    if ((EDGE || F64 || bd.narrow != 1) && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
+    if ((EDGE || bd.narrow != 1) && !QI_BDBG(4)) fft4096<T, 1>(v, buf, tw256, w, tid, col);
     QI_BSTAMP(3);
     if (pending >= 0 && tid == 0) {
       double r = 0.0;

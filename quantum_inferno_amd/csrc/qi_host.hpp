@@ -340,6 +340,10 @@ struct qi_plan {
   // Nyquist bins -- the native run leaves them out and a pass of the hipFFT engine over just these rows follows it
   // (run_stx_leftover); any other case hands the whole table to the hipFFT engine as before
   int32_t stx_left_lo = -1, stx_left_n = 0;
+  int native_min_log2n = 14;    // shortest power-of-two record the zoom / block engines are tried on (below: the hipFFT engine).
+                                // float32: 2^14 (round 5: 54 / 69 us per call against 97 / 230 on the hipFFT engine at orders 3 / 12);
+                                // float64: 2^15 (at 2^14 the float64 zoom's small grids go through hipFFT launch by launch: slower)
+  int native_blk64_narrow = 1;  // float64 block engine: bands whose weights above 2^-52 of the peak span <= 256 bins skip the first pass of the inverse transform (sparse_head16)
   int native_blk64_wtab = 1;  // float64 block engine: Gaussian filter weights from a plan-time table instead of sixteen exp2 per band and thread
   int native_z64_block_from = 4;  // a band that needs coarse-grid level >= this (0-based) goes to the block engine when its atom is short enough
   int native_z64_coarse = 3;  // coarse-grid levels whose coarse stage is one launch of in-LDS plane transforms (the finer ones: hipFFT)

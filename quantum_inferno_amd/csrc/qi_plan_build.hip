@@ -20,7 +20,7 @@ bool native_wanted(const qi_plan* p, int kind) {
   // Stockwell and styx tables usually have no band for the two-pass kernels (every band is a zoom, block or split
   // band), and those engines -- in float32 and, since round 4, their float64 twins (float64 zoom, k_block64, split bands) --
   // take any power-of-two length from 2^15: the table build decides
-  return kind != 1 && is_pow2(p->n) && p->n >= (1 << 15) && Lf <= (1ll << 26);
+  return kind != 1 && is_pow2(p->n) && p->n >= ((int64_t)1 << p->native_min_log2n) && Lf <= (1ll << 26);
 }
 
 // Widest spectrum support (bins) of a band that keeps a compact bank row: the one-pass loader's limit, or -- float64 with
@@ -458,7 +458,10 @@ int finish_block_table(qi_plan* p, int kind, int demod, const std::vector<BlockP
           set_error("block engine: float64 tables take analytic (Gaussian) bands only");
           return QI_ERR_STATE;
         }
-        if (!F64 && b.analytic && p->native_blk_narrow && 2.0 * half + 2.0 <= 256.0) {
+        // (float64 since round 5: `half` is then the 2^-52 half-width, the weight comes from the table -- bands of the 512- and
+        // 1024-sample reach groups; analytic = 2, an aliased spectrum, is not narrow)
+        if ((!F64 || (b.analytic == 1 && p->native_blk64_wtab && p->native_blk64_narrow)) && b.analytic && p->native_blk_narrow &&
+            2.0 * half + 2.0 <= 256.0) {
           b.narrow = 1;
           b.klo = is_long ? (int32_t)long_window(picks[r])
                           : (int32_t)((((int64_t)std::llround(kappa) - 128) % native::kBlk + native::kBlk) % native::kBlk);

@@ -524,7 +524,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
   }
   char* w = p->ws;
   QI_LAYOUT_BEGIN(p, kind == 0 ? "run_native styx" : (kind == 1 ? "run_native atoms" : "run_native stx"), finishing);
-  bool carving_shared = share;  // (the first region: spectra the CWT run of a joint tile left behind)
+  [[maybe_unused]] bool carving_shared = share;  // (the first region: spectra the CWT run of a joint tile left behind)
   auto carve = [&](size_t bytes) {
     char* r = w;
     w += align_up(bytes * Ct);
@@ -1160,6 +1160,8 @@ int run_native64(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tf
       b.power_scale = power_scale;
       b.eps = eps;
       b.two_over_n = (float)(2.0 / (double)n);
+      b.debug = p->native_debug;
+      b.stamps = p->blk_stamps;
       p->prof.begin(st, QI_STAGE_BLOCK);
       if (b.nedge_items > 0 && !p->side) {
         QI_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));

@@ -16,7 +16,7 @@ import torch  # noqa: E402,F401  (engine imports it)
 from quantum_inferno_amd import engine, scales_dyadic as scales  # noqa: E402
 
 ORDERS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
-LOG2N = [15, 16, 17, 18, 19, 20, 21, 22]
+LOG2N = [14, 15, 16, 17, 18, 19, 20, 21, 22]
 RECORDS = [1, 4, 16, 64]
 
 

@@ -1,7 +1,7 @@
 // Host sanitizer walk ("build variants with -fsanitize=address for host code").  The library's translation units,
 // compiled for the HOST ONLY under AddressSanitizer + UndefinedBehaviorSanitizer and linked with a stand-in HIP runtime
 // (fake_hip.cpp: kernels do not run, device memory is host memory), are driven through the C ABI over every
-//   order 1 .. 12  x  record length 2^15 .. 2^22  x  float32 / float64  x  1 / 4 / 16 / 64 records
+//   order 1 .. 12  x  record length 2^14 .. 2^22  x  float32 / float64  x  1 / 4 / 16 / 64 records
 // with the band tables the Python host code makes (gen_tables.py) and the scratch TfrPlan.workspace_for sizes for that batch:
 // plan build (band assignment, zoom classes, block item lists, split bands), qi_cwt_stx / qi_cwt / qi_stx with several output
 // sets (scratch carving, tiles, joint launches, launch geometry).  Checked on the way:

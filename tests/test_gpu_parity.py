@@ -1113,7 +1113,7 @@ def test_fused_call_other_requests_and_tiles():
     small.close()
 
 
-@pytest.mark.parametrize("log2n,order", [(15, 3), (15, 12), (16, 3), (17, 3), (16, 12), (17, 6), (18, 3), (19, 3), (21, 3), (22, 3), (19, 12), (21, 12), (21, 6)])
+@pytest.mark.parametrize("log2n,order", [(14, 3), (14, 12), (15, 3), (15, 12), (16, 3), (17, 3), (16, 12), (17, 6), (18, 3), (19, 3), (21, 3), (22, 3), (19, 12), (21, 12), (21, 6)])
 def test_native_engine_other_lengths(log2n, order):
     """Stockwell transform and styx CWT at the other power-of-two lengths the native engine takes (their order-3 band
     tables need only the zoom and block engines -- the CWT's longest atoms as split bands -- which are not tied to the
