@@ -1411,6 +1411,12 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
   const int64_t ch = blockIdx.z;
   const cplx<T>* __restrict__ X = a.X + ch * (a.Lf << a.x_shift);
   cplx<T> v[16];
+#ifdef QI_NATIVE_DEBUG
+  if (a.debug & 256) {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) v[b] = mk<T>((T)(col + b), (T)tau1);
+  } else
+#endif
   zoom_gather16<T, STX, NF>(a, bd, tau1, col, X, v);
   {
     float s, c;
@@ -1423,8 +1429,14 @@ __device__ __forceinline__ void zoom_coarse_plane_gather(const ZoomArgs<T>& a, c
     sincospif((float)col * (2.0f / 4096.0f), &s, &c);
     w = mk<T>((T)c, (T)s);
   }
+#ifdef QI_NATIVE_DEBUG
+  if (!(a.debug & 512))
+#endif
   fft4096<T, 1>(v, buf, tw256, w, tid, col);
   cplx<T>* __restrict__ plane = a.coarse + ((int64_t)ch * a.planes + plane_i) * kBlk + col;
+#ifdef QI_NATIVE_DEBUG
+  if ((a.debug & 1024) && v[3].x != (T)12345.678f) return;
+#endif
 #pragma unroll
   for (int c = 0; c < 16; ++c) plane[256 * c] = v[brev(c, 4)];
 }
@@ -1807,7 +1819,8 @@ int launch_zoom_coarse_gather2<float>(const ZoomArgs<float>& a0, const ZoomArgs<
   }
   dim3 grid((unsigned)(((a0.planes + a2.planes) + 63) / 64 * 64), 1, (unsigned)n_channels);
   // few records: a couple of workgroups per CU, each waiting on its loads -- twice as many in flight
-  if (n_channels > 2) k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
+  static const int nf_env = tune_env("QI_NATIVE_COARSE_NF") ? atoi(tune_env("QI_NATIVE_COARSE_NF")) : 0;
+  if (nf_env == 8 || (nf_env == 0 && n_channels > 2)) k_zoom_coarse2g<float, 8><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   else k_zoom_coarse2g<float, 16><<<grid, kBlkThreads, 0, st>>>(a0, a2);
   QI_LAUNCH_CHECK();
   return QI_OK;

@@ -233,6 +233,7 @@ struct ZoomArgs {
   const cplx<T>* Hc;       // compact bank (Gabor kinds)
   cplx<T>* split_part;     // [C][split_rows][n]: the split bands (BandDesc::add_row) leave their samples here, see k_zoom
   int32_t split_rows;
+  int32_t debug;  // QI_NATIVE_DEBUG builds, timing experiments of the coarse stage: 256 no gather, 512 no transform, 1024 no stores
   cplx<T>* coarse;         // [C][planes][4096]: per band [P][4096], P = M_g / 4096: sample tau = P tau2 + tau1 at [tau1][tau2]
   int32_t stx;             // Stockwell: bands are at baseband already, no carrier
   int32_t lane_off;        // output sample t is full-length sample f = 64 (tau + tau_off) + lane - lane_off

@@ -711,6 +711,7 @@ int run_native(qi_plan* p, int kind, const void* sig_v, int64_t C, const qi_tfr_
       z.eps = (T)(out->eps == 0.0 ? 2.220446049250313e-16 : out->eps);
       z.split_part = zadd;
       z.split_rows = nsplit;
+      z.debug = p->native_debug;
       int chunk0 = 0;
       for (int g = 0; g < NL; ++g) {
         z.lvl_count[g] = zcount[g];
