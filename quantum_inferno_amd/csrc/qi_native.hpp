@@ -270,7 +270,10 @@ template <typename T>
 int launch_zoom_coarse_gather2(const ZoomArgs<T>& a0, const ZoomArgs<T>& a2, int64_t n_channels, hipStream_t st);
 // ---- float64 zoom (qi_zoom64.hip) ------------------------------------------------------------------------------------
 constexpr int kZ64Taps = 16;       // interpolator taps (oversampling >= 4: 2.8e-12 of a unit tone)
-constexpr int kZ64Tile = 4096;     // panel samples per workgroup and band (one partial slot per band and tile)
+#ifndef QI_Z64_TILE
+#define QI_Z64_TILE 2048  // (round 5: 4096 -> 2048 halves the kernel's LDS, four workgroups per CU instead of three: -1.6 % of the zoom stage; 1024: slower)
+#endif
+constexpr int kZ64Tile = QI_Z64_TILE;  // panel samples per workgroup and band of k_z64_interp (one partial slot per band and tile)
 constexpr int kZ64Levels = 5;      // coarse grids of Lf / 64 ... Lf / 4 samples (a band is oversampled >= 4 times on its grid)
 constexpr int kZ64Pad = 16;        // a band's coarse array is [kZ64Pad | M | kZ64Pad] samples: the pads repeat the other end (k_z64_pad)
 struct Z64Args {
