@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
   double* __restrict__ col0 = colv + tid;
 #pragma unroll
   for (int r = 0; r < R; ++r) col0[r * kZ64Threads] = 0.0;
-  double mx = 0.0, plogp = 0.0;
+  double mx = 0.0, plogp = 0.0, ptot = 0.0;  // (ptot: the total power when no per-time sums are kept)
+  const bool want_time = a.time_part != nullptr;
   for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
     const BandDesc bd = load_uniform(a.bands + jj);
     const cd* __restrict__ C = a.Z + ((int64_t)ch * a.nbands + jj) * (a.M + 2 * kZ64Pad) + kZ64Pad;
@@ -151,12 +152,13 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
       const double m2 = norm2(z.x, z.y);
       if (bits_row) bits_row[tt] = log2_t(sqrt_t(m2) + a.eps);
       const double p = mul_rn(pscale, m2);
-      col0[r * kZ64Threads] += p;
+      if (want_time) col0[r * kZ64Threads] += p;
       rowacc += p;
       mx = max_t(mx, p);
       pl += plog2p_flat(p, ltab);
     }
     plogp += pl;
+    ptot += rowacc;
     if (a.part_band && !part) {  // (the same for every thread)
       const double rs = wave_sum(rowacc);
       if (lane == 0) s_red[wv] = rs;
@@ -176,6 +178,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
     tot += v;
     if (time_row) time_row[t_first + (uint32_t)r * kZ64Threads] = v;
   }
+  if (!want_time) tot = ptot;
   if (a.part_stat) {
     const double r0 = wave_max(mx), r1 = wave_sum(tot), r2 = wave_sum(plogp);
     if (lane == 0) {
@@ -250,7 +253,8 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
   double* __restrict__ col0 = colv + wv * kZ64FineWave + lane;
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) col0[s * kWave] = 0.0;
-  double mx = 0.0, plogp = 0.0;
+  double mx = 0.0, plogp = 0.0, ptot = 0.0;  // (ptot: the total power when no per-time sums are kept)
+  const bool want_time = a.z.time_part != nullptr;
   const uint32_t tt0 = t_wave + (uint32_t)lane;
   const int64_t zstride = a.z.M + 2 * kZ64Pad;
   constexpr int NEED = STEPS * S + N - 1;  // coarse samples one wave needs per band
@@ -332,7 +336,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
         // measured neutral to 1 % faster at order 12 x 4 records)
         if (COEF && !QI_ZDBG(1)) stream_store(coef_row + tt0 + (uint32_t)(kWave * (g * GS + s)), z);
         const double p = mul_rn(pscale, norm2(z.x, z.y));
-        if (!QI_ZDBG(8)) col0[(g * GS + s) * kWave] += p;
+        if (want_time && !QI_ZDBG(8)) col0[(g * GS + s) * kWave] += p;  // (no per-time marginal asked for: no LDS traffic for it)
         rowacc += p;
         mx = max_t(mx, p);
         if (!QI_ZDBG(4)) pl += plog2p_flat(p, ltab);
@@ -354,6 +358,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
       }
     }
     plogp += pl;
+    ptot += rowacc;
     if (a.z.part_band && !part) {
       const double rs = wave_sum(rowacc);
       if (lane == 0) a.z.part_band[((int64_t)ch * a.z.panel_bands + out_band) * a.z.pb_stride + slot] = rs;
@@ -368,6 +373,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
     tot += v;
     if (time_row) time_row[tt0 + (uint32_t)(kWave * s)] = v;
   }
+  if (!want_time) tot = ptot;
   if (a.z.part_stat) {
     const double r0 = wave_max(mx), r1 = wave_sum(tot), r2 = wave_sum(plogp);
     if (lane == 0) {

@@ -263,17 +263,27 @@ class TfrPlan:
                 from .dist import reduced_slots
 
                 slots = reduced_slots(n_ch, n_b, self.n, self.rdtype)
-                if reduced_out is not None:  # caller-provided slice (e.g. of one buffer for several transforms)
+                if reductions == "band":
+                    # band powers and statistics only, no per-time marginal: the kernels then write (and the tail reads) no
+                    # per-time planes at all -- what a streaming job that keeps no per-time power asks for (stream.py)
+                    if reduced_out is not None:
+                        raise ValueError('reductions="band" has no gather layout: reduced_out does not apply')
+                    small = torch.empty(n_ch * (n_b + 4), dtype=torch.float64, device=dev)
+                    res.power_band = small[: n_ch * n_b].view(n_ch, n_b)
+                    res.stats = small[n_ch * n_b :].view(n_ch, 4)
+                    slots = None
+                elif reduced_out is not None:  # caller-provided slice (e.g. of one buffer for several transforms)
                     if reduced_out.dtype != torch.float64 or reduced_out.numel() != slots or not reduced_out.is_contiguous():
                         raise ValueError(f"reduced_out must be a contiguous float64 tensor of {slots} elements")
                     res.reduced = reduced_out
                 else:
                     res.reduced = torch.empty(slots, dtype=torch.float64, device=dev)
-                o1 = res.reduced.numel() - n_ch * (n_b + 4)
-                o2 = o1 + n_ch * n_b
-                res.power_time = res.reduced[:o1].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
-                res.power_band = res.reduced[o1:o2].view(n_ch, n_b)
-                res.stats = res.reduced[o2:].view(n_ch, 4)
+                if slots is not None:
+                    o1 = res.reduced.numel() - n_ch * (n_b + 4)
+                    o2 = o1 + n_ch * n_b
+                    res.power_time = res.reduced[:o1].view(self.rdtype)[: n_ch * self.n].view(n_ch, self.n)
+                    res.power_band = res.reduced[o1:o2].view(n_ch, n_b)
+                    res.stats = res.reduced[o2:].view(n_ch, 4)
         desc = _lib.TfrOut(
             coef=_lib.ptr(res.coef),
             bits=_lib.ptr(res.bits),

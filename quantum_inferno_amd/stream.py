@@ -107,8 +107,8 @@ class StreamPipeline:
             ...
 
     `host_records`: NumPy array / memmap [channels, n_total] (any real dtype; converted to the plan's on the way into
-    the pinned buffer).  Every yielded item owns its reduced products.  keep_time=False drops the per-time power of a
-    chunk (8 MB per record in float64) from the copies that are kept."""
+    the pinned buffer).  Every yielded item owns its reduced products.  keep_time=False: the per-time power of a chunk
+    (8 MB per record in float64) is neither kept nor computed (`reductions="band"`: band powers, maximum, total, entropy)."""
 
     def __init__(self, plan: engine.TfrPlan, host_records, hop: int, block: int = 16, transforms=("cwt", "stx"),
                  power_scale: float = 1.0, keep_time: bool = True):
@@ -123,6 +123,8 @@ class StreamPipeline:
             if t not in ("cwt", "stx"):
                 raise ValueError(f"unknown transform {t!r}: 'cwt' and / or 'stx'")
         self.power_scale, self.keep_time = power_scale, keep_time
+        # (no per-time power kept: it is not computed either -- no per-time planes written or summed, round 5)
+        self._reductions = True if keep_time else "band"
         self.items = work_items(self.sig.shape[0], self.block, self.sig.shape[1], plan.n, self.hop)
         np_dtype = np.float64 if plan.rdtype == torch.float64 else np.float32
         # (a plan on the CPU exists only as the stand-in of bench.py --stub: the item walk without streams or pinning)
@@ -171,14 +173,14 @@ class StreamPipeline:
             res = {}
             if self.transforms == ("cwt", "stx"):
                 key = ("both", cb)
-                self._out[key] = self.plan.cwt_stx(x, coef=False, reductions=True, power_scale=self.power_scale,
+                self._out[key] = self.plan.cwt_stx(x, coef=False, reductions=self._reductions, power_scale=self.power_scale,
                                                    out=self._out.get(key))
                 res["cwt"], res["stx"] = self._out[key]
             else:
                 for t in self.transforms:
                     key = (t, cb)
                     fn = self.plan.cwt if t == "cwt" else self.plan.stx
-                    self._out[key] = fn(x, coef=False, reductions=True, power_scale=self.power_scale, out=self._out.get(key))
+                    self._out[key] = fn(x, coef=False, reductions=self._reductions, power_scale=self.power_scale, out=self._out.get(key))
                     res[t] = self._out[key]
             if self._gpu:
                 self._consumed[j].record(compute)

@@ -1336,3 +1336,30 @@ def test_stockwell_rows_behind_the_native_run(dtype, log2n, order):
     assert torch.allclose(lean.stats[:, :3], a.stats[:, :3], rtol=1e-12 if f64 else 1e-5)
     nat.close()
     ref.close()
+
+
+@pytest.mark.parametrize("dtype,n,order", [(np.float32, 1 << 18, 3), (np.float64, 1 << 16, 6), (np.float32, 3000, 3), (np.float64, 1 << 20, 12)])
+def test_band_only_reductions_match_full(dtype, n, order):
+    """reductions="band" (what the streaming pipeline asks for when no per-time power is kept: band powers, maximum, total
+    and entropy sums, NO per-time marginal -- the kernels then write no per-time planes and the tail sums none) against the
+    full reductions, on the native engines in both precisions and on the hipFFT engine, stored and streaming, separate and
+    joint calls."""
+    fs, C = 800.0, 3
+    rng = np.random.default_rng(n % 1000 + order)
+    x = np.stack([orc.synth_chirp(n, fs, c, C, dtype) for c in range(C)]) + (0.1 * rng.standard_normal((C, n))).astype(dtype)
+    x = torch.from_numpy(x).cuda()
+    plan = _plan_with_all(n, fs, order, dtype, channels=C)
+    rt = 1e-5 if dtype == np.float32 else 1e-11
+    for coef in (True, False):
+        full = {"cwt": plan.cwt(x, coef=coef, reductions=True), "stx": plan.stx(x, coef=coef, reductions=True)}
+        lean = {"cwt": plan.cwt(x, coef=coef, reductions="band"), "stx": plan.stx(x, coef=coef, reductions="band")}
+        joint = dict(zip(("cwt", "stx"), plan.cwt_stx(x, coef=coef, reductions="band")))
+        for name in ("cwt", "stx"):
+            for got in (lean[name], joint[name]):
+                assert got.power_time is None and got.reduced is None
+                assert torch.allclose(got.power_band, full[name].power_band, rtol=rt, atol=0.0), (name, coef)
+                assert torch.allclose(got.stats[:, :3], full[name].stats[:, :3], rtol=rt, atol=0.0), (name, coef)
+                assert torch.allclose(got.entropy_bits, full[name].entropy_bits, rtol=rt)
+                if coef:
+                    assert float((got.coef - full[name].coef).abs().max()) <= 2e-6 * float(full[name].coef.abs().max())
+    plan.close()
