@@ -63,8 +63,14 @@ __global__ void __launch_bounds__(256) k_z64_gather(Z64Args a) {
 // same address: broadcast).
 // LOG2D (the grid's coarse step) is a compile-time constant: consecutive samples of a thread then read overlapping
 // windows at known offsets (on the coarsest grid 12 of the 16 taps are the previous sample's), and the loads are shared.
+#ifndef QI_Z64_INTERP_WAVES
+#define QI_Z64_INTERP_WAVES 1
+#endif
+#ifndef QI_Z64_INTERP_UNROLL
+#define QI_Z64_INTERP_UNROLL 2
+#endif
 template <int KIND, int LOG2D>
-__global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
+__global__ void __launch_bounds__(kZ64Threads, QI_Z64_INTERP_WAVES) k_z64_interp(Z64Args a) {
   constexpr int NW = kZ64Threads / kWave, N = kZ64Taps;
   constexpr int R = kZ64Tile / kZ64Threads;  // samples per thread and band
   __shared__ cd win[((R * kZ64Threads) >> LOG2D) + N + 1];
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
     const double pscale = part ? 0.0 : a.power_scale;
     double rowacc = 0.0, pl = 0.0;
     __syncthreads();
-#pragma unroll 2
+#pragma unroll QI_Z64_INTERP_UNROLL
     for (int r = 0; r < R; ++r) {
       const cd* __restrict__ s = win + idx0 + (uint32_t)r * istep;
       double zr[2] = {0.0, 0.0}, zi[2] = {0.0, 0.0};  // two accumulation chains per part (the taps are independent)
@@ -177,6 +183,193 @@ __global__ void __launch_bounds__(kZ64Threads) k_z64_interp(Z64Args a) {
     const double v = col0[r * kZ64Threads];
     tot += v;
     if (time_row) time_row[t_first + (uint32_t)r * kZ64Threads] = v;
+  }
+  if (!want_time) tot = ptot;
+  if (a.part_stat) {
+    const double r0 = wave_max(mx), r1 = wave_sum(tot), r2 = wave_sum(plogp);
+    if (lane == 0) {
+      s_fin[0][wv] = r0;
+      s_fin[1][wv] = r1;
+      s_fin[2][wv] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < NW; ++q) {
+        m = s_fin[0][q] > m ? s_fin[0][q] : m;
+        s1 += s_fin[1][q];
+        s2 += s_fin[2][q];
+      }
+      double* o = a.part_stat + ((int64_t)ch * a.stat_stride + (int64_t)(a.chunk_base + blockIdx.y) * a.stat_nblk + tile) * 3;
+      o[0] = m;
+      o[1] = s1;
+      o[2] = s2;
+    }
+  }
+}
+
+// ---- interpolation on the matrix pipe (round 5): the grids of Lf / 16 and Lf / 8 samples ---------------------------------
+// The 16-tap interpolation is a small dense contraction: for 16 consecutive coarse intervals i and the D phases ph of an
+// interval, out[i][ph] = sum_j c[m0 - 7 + i + j] w[ph][j] = (Hankel matrix of the window, 16 x 16) x (weights^T, 16 x D).
+// With D = 16 that is v_mfma_f64_16x16x4_f64 four times per part (real, imaginary), and the result layout of that
+// instruction -- lane l, register r holds row (l >> 4) + 4 r, column l & 15 -- IS the panel order: sample
+// t0 + 16 ((l >> 4) + 4 r) + (l & 15) = t0 + l + 64 r, consecutive lanes = consecutive samples, register r = wave-step r.  D = 8:
+// the columns are (interval parity e, phase), the rows every second interval, the contraction runs over j' = j + e < 17
+// (padded to 20: five instructions) with weights w[ph][j' - e].  Per 256 outputs and part: 4 (5) ds_read_b64 of a lane's
+// Hankel element from the wave's window in LDS + 4 (5) MFMA, against 64 x (16 ds_read_b128 + 16 fused multiply-adds) per
+// lane in k_z64_interp -- the vector pipe keeps the epilogue (carrier, powers, entropy logarithm, stores), which was 45 of
+// that kernel's 82 instructions per output.  Same launch geometry, partial-sum layout and arithmetic per tap as
+// k_z64_interp (one workgroup = one tile of kZ64Tile samples, a wave owns a quarter of it); the sums of products are formed
+// in the order of the instruction (k = 0 .. 3 within a block of four taps, blocks in turn) -- float64 rounding, no more.
+// No other kernel of the path is a contraction large enough for the matrix pipe.
+typedef double qi_d4 __attribute__((ext_vector_type(4)));
+#ifndef QI_Z64_MX_WAVES
+#define QI_Z64_MX_WAVES 4
+#endif
+template <int KIND, int LOG2D, bool COEF>
+__global__ void __launch_bounds__(kZ64Threads, QI_Z64_MX_WAVES) k_z64_mfma(Z64Args a) {
+  static_assert(LOG2D == 4 || LOG2D == 3, "grids of Lf / 16 and Lf / 8 samples");
+  constexpr int NW = kZ64Threads / kWave, N = kZ64Taps;
+  constexpr int WSAMP = kZ64Tile / NW;           // panel samples per wave and band
+  constexpr int STEPS = WSAMP / kWave;           // wave-steps (64 samples) per wave and band
+  constexpr int GROUPS = STEPS / 4;              // 256-sample groups = one accumulator tile each
+  constexpr int KB = LOG2D == 4 ? 4 : 5;         // blocks of four taps per contraction
+  constexpr int ROWMUL = LOG2D == 4 ? 1 : 2;     // coarse samples per row of the tile
+  constexpr int GSTEP = 256 >> LOG2D;            // coarse samples per group
+  constexpr int NWIN = (WSAMP >> LOG2D) + 4 * KB;  // window of one wave (>= WSAMP / D + N - 1 + what the padded taps reach)
+  constexpr int NPRE = (NWIN + kWave - 1) / kWave;
+  static_assert(STEPS % 4 == 0 && GROUPS >= 1, "a wave's share is a whole number of 256-sample groups");
+  __shared__ double win_re[NW][NWIN], win_im[NW][NWIN];
+  __shared__ double s_red[NW];
+  __shared__ double s_fin[3][NW];
+  __shared__ double ltab[128][2];
+  __shared__ double colv[kZ64Tile];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+  if (tid < 128) {
+    ltab[tid][0] = kLog2Tab[tid][0];
+    ltab[tid][1] = kLog2Tab[tid][1];
+  }
+  const int64_t ch = blockIdx.z, tile = blockIdx.x, n = a.n;
+  const uint32_t off = KIND == 2 ? 0u : (uint32_t)(n / 2);
+  const uint32_t lmask = (uint32_t)a.Lf - 1u, mmask = (uint32_t)a.M - 1u;
+  const uint32_t t_wave = (uint32_t)tile * (uint32_t)kZ64Tile + (uint32_t)(wv * WSAMP);  // first panel sample of this wave
+  const uint32_t tau_wave = (t_wave + off) & lmask;       // (a multiple of 256: every group starts on a coarse sample)
+  const uint32_t m_wave = (tau_wave >> LOG2D) - (uint32_t)(N / 2 - 1);  // first window sample (mod M)
+  // B operand: lane l supplies weights^T[k = 4 q + (l >> 4)][column l & 15]
+  double wb[KB];
+  {
+    const int kq = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int q = 0; q < KB; ++q) {
+      const int jp = 4 * q + kq;  // tap index j' of the (padded) contraction
+      if (LOG2D == 4) {
+        wb[q] = a.weights[col * N + jp];
+      } else {
+        const int e = col >> 3, ph = col & 7, j = jp - e;
+        wb[q] = (j >= 0 && j < N) ? a.weights[ph * N + j] : 0.0;
+      }
+    }
+  }
+  // A operand: lane l reads window sample ROWMUL (l & 15) + (l >> 4) + 4 q of its group
+  const int a_off = ROWMUL * (lane & 15) + (lane >> 4);
+  double* __restrict__ col0 = colv + wv * WSAMP + lane;
+  const bool want_time = a.time_part != nullptr;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) col0[s * kWave] = 0.0;
+  double mx = 0.0, plogp = 0.0, ptot = 0.0;
+  const uint32_t tt0 = t_wave + (uint32_t)lane;
+  // a wave's window comes through registers, requested ONE BAND AHEAD: the global loads of band j + 1 fly while band j is
+  // interpolated (k_z64_interp waits for them at the top of every band)
+  const int64_t zstride = a.M + 2 * kZ64Pad;
+  cd pre[NPRE];
+  auto request = [&](int band) {
+    const cd* __restrict__ C = a.Z + ((int64_t)ch * a.nbands + band) * zstride + kZ64Pad;
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+      const int i = lane + q * kWave;
+      pre[q] = C[(m_wave + (uint32_t)(i < NWIN ? i : NWIN - 1)) & mmask];
+    }
+  };
+  if ((int)blockIdx.y < a.nbands) request(blockIdx.y);
+  for (int jj = blockIdx.y; jj < a.nbands; jj += gridDim.y) {
+    const BandDesc bd = load_uniform(a.bands + jj);
+    __syncthreads();  // the previous band's readers are done with the windows (and with s_red)
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+      const int i = lane + q * kWave;
+      if (i < NWIN) {
+        win_re[wv][i] = pre[q].x;
+        win_im[wv][i] = pre[q].y;
+      }
+    }
+    if (jj + (int)gridDim.y < a.nbands) request(jj + gridDim.y);
+    const int64_t orow = ((int64_t)ch * a.panel_bands + bd.out_band) * n;
+    const bool part = bd.add_row != 0;  // split band: the tapered part only, to split_part, counts for nothing here
+    cd* __restrict__ coef_row =
+        part ? a.split_part + ((int64_t)ch * a.split_rows + (bd.add_row - 1)) * n : (COEF ? a.coef + orow : nullptr);
+    const bool carrier = KIND != 2 && coef_row != nullptr;
+    cd ph = mk<double>(1.0, 0.0), st = ph;
+    if (carrier) {
+      const uint32_t kc = (uint32_t)(bd.k_lo + bd.k_len / 2);
+      double c, s;
+      unit_root_t<double>((kc * (tau_wave + (uint32_t)lane - (KIND == 0 ? 1u : 0u))) & lmask, a.two_over_len, &c, &s);
+      ph = mk<double>(c, s);
+      unit_root_t<double>((kc * (uint32_t)kWave) & lmask, a.two_over_len, &c, &s);
+      st = mk<double>(c, s);
+    }
+    double* __restrict__ bits_row = a.bits && !part ? a.bits + orow : nullptr;
+    const double pscale = part ? 0.0 : a.power_scale;
+    double rowacc = 0.0, pl = 0.0;
+    __syncthreads();
+#pragma unroll 1  // (unrolled, the compiler hoists every group's window reads to the top: 256 registers)
+    for (int g = 0; g < GROUPS; ++g) {
+      qi_d4 zr = {0.0, 0.0, 0.0, 0.0}, zi = {0.0, 0.0, 0.0, 0.0};
+      const double* __restrict__ wr = &win_re[wv][g * GSTEP + a_off];
+      const double* __restrict__ wi = &win_im[wv][g * GSTEP + a_off];
+#pragma unroll
+      for (int q = 0; q < KB; ++q) {
+        zr = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[4 * q], wb[q], zr, 0, 0, 0);
+        zi = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[4 * q], wb[q], zi, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // register r = wave-step 4 g + r: sample tt0 + 64 (4 g + r)
+        cd z = mk<double>(zr[r], zi[r]);
+        if (carrier) {
+          z = cmul_rn(z, ph);
+          ph = cmul_rn(ph, st);
+        }
+        const uint32_t tt = tt0 + (uint32_t)(kWave * (4 * g + r));
+        if (coef_row) stream_store(coef_row + tt, z);
+        const double m2 = norm2(z.x, z.y);
+        if (bits_row) bits_row[tt] = log2_t(sqrt_t(m2) + a.eps);
+        const double p = mul_rn(pscale, m2);
+        if (want_time) col0[(4 * g + r) * kWave] += p;
+        rowacc += p;
+        mx = max_t(mx, p);
+        pl += plog2p_flat(p, ltab);
+      }
+    }
+    plogp += pl;
+    ptot += rowacc;
+    if (a.part_band && !part) {  // (the same for every thread)
+      const double rs = wave_sum(rowacc);
+      if (lane == 0) s_red[wv] = rs;
+      __syncthreads();
+      if (tid == 0) {
+        double t = 0.0;
+        for (int q = 0; q < NW; ++q) t += s_red[q];
+        a.part_band[((int64_t)ch * a.panel_bands + bd.out_band) * a.pb_stride + tile] = t;
+      }
+    }
+  }
+  double tot = 0.0;
+  double* __restrict__ time_row = a.time_part ? a.time_part + ((int64_t)ch * a.chunk_total + a.chunk_base + blockIdx.y) * n : nullptr;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const double v = col0[s * kWave];
+    tot += v;
+    if (time_row) time_row[tt0 + (uint32_t)(kWave * s)] = v;
   }
   if (!want_time) tot = ptot;
   if (a.part_stat) {
@@ -417,6 +610,20 @@ void launch_fine_cls(const Z64FineArgs& a, dim3 grid, hipStream_t st) {
 
 template <int KIND>
 int launch_interp_v(const Z64Args& a, dim3 grid, hipStream_t st) {
+  // the grids of Lf / 16 and Lf / 8 samples: interpolation on the matrix pipe (QI_NATIVE_Z64_MFMA=0: the LDS-window kernel)
+  static const bool use_mfma = !(tune_env("QI_NATIVE_Z64_MFMA") && atoi(tune_env("QI_NATIVE_Z64_MFMA")) == 0);
+  if (use_mfma && (a.log2d == 4 || a.log2d == 3) && kZ64Tile % (4 * 256) == 0 && (a.n / 2) % 256 == 0) {
+    const bool coef = a.coef != nullptr;
+    if (a.log2d == 4) {
+      if (coef) k_z64_mfma<KIND, 4, true><<<grid, kZ64Threads, 0, st>>>(a);
+      else k_z64_mfma<KIND, 4, false><<<grid, kZ64Threads, 0, st>>>(a);
+    } else {
+      if (coef) k_z64_mfma<KIND, 3, true><<<grid, kZ64Threads, 0, st>>>(a);
+      else k_z64_mfma<KIND, 3, false><<<grid, kZ64Threads, 0, st>>>(a);
+    }
+    QI_LAUNCH_CHECK();
+    return QI_OK;
+  }
   switch (a.log2d) {
     case 6: k_z64_interp<KIND, 6><<<grid, kZ64Threads, 0, st>>>(a); break;
     case 5: k_z64_interp<KIND, 5><<<grid, kZ64Threads, 0, st>>>(a); break;
