@@ -12,7 +12,7 @@ import os
 import re
 import sys
 
-STAGES = {"zoom": ("k_zoom2", "k_zoom<", "k_z64_fine", "k_z64_interp"), "block": ("k_block",)}
+STAGES = {"zoom": ("k_zoom2", "k_zoom<", "k_z64_fine", "k_z64_interp", "k_z64_mfma"), "block": ("k_block",)}
 TAILS = ("k_tail2", "k_tail<")  # one dispatch per stage span (a joint tile's tail, or a table run's)
 LEGS = {"cfg1": ("f32", 20, 3, 1), "cfg2": ("f32", 20, 12, 64), "f64": ("f64", 20, 12, 4)}
 
@@ -20,10 +20,10 @@ LEGS = {"cfg1": ("f32", 20, 3, 1), "cfg2": ("f32", 20, 12, 64), "f64": ("f64", 2
 def counters(d, ctr):
     per = collections.defaultdict(float)
     count = collections.Counter()
-    files = glob.glob(os.path.join(d, ctr, "**", "*_counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(d, ctr, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         return None, None
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader(open(files[-1])):  # (the newest pass)
         if r["Counter_Name"] != ctr:
             continue
         m = re.search(r"(k_\w+<?)", r["Kernel_Name"])
