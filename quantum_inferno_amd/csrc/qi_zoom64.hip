@@ -427,6 +427,9 @@ constexpr int z64f_group(int cls) {
 // the wave's first one.  A band's coarse array is [kZ64Pad | M | kZ64Pad] samples, the pads holding the other end's samples
 // (k_z64_pad): a wave's window is always a run of consecutive samples -- lane i loads sample m_wave + i (16 bytes, a band
 // ahead), and the lanes' arithmetic takes sample e from lane e through scalar registers (v_readlane).
+#ifndef QI_Z64_FLIGHT
+#define QI_Z64_FLIGHT 2
+#endif
 template <int KIND, int CLS, bool COEF>
 __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int row, const double (*ltab)[2], double* __restrict__ colv) {
   constexpr int LEVEL = z64f_level(CLS), LOG2D = 6 - LEVEL, S = 1 << LEVEL, N = z64f_ntap(CLS), WL = N + S - 1;
@@ -533,7 +536,7 @@ __device__ __forceinline__ void z64_fine_class(const Z64FineArgs& a, const int r
         rowacc += p;
         mx = max_t(mx, p);
         if (!QI_ZDBG(4)) pl += plog2p_flat(p, ltab);
-        if (s & 1) {  // two outputs in flight: more only cost registers (the fence pins the running sums: without it every
+        if ((s & (QI_Z64_FLIGHT - 1)) == QI_Z64_FLIGHT - 1) {  // two outputs in flight: more only cost registers (round 5, four / eight: zoom stage +3 % / +20 %) (the fence pins the running sums: without it every
           // power of the band stays in registers until a deferred chain of maxima at the end of the loop)
           asm volatile("" : "+v"(mx), "+v"(pl), "+v"(rowacc));
           __builtin_amdgcn_sched_barrier(0);
