@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs[4] streaming sample: vector instructions and HBM bytes per streamed item (16 records x 2^20, order 12, float64),
 # summed over every kernel of the run and divided by the items (separate --pmc passes; FETCH_SIZE x 2, KiB units)
-out=$GRAFT_REPO_ROOT/gpurun_out/${1:-r4_cfg4_pmc}
+out=$GRAFT_REPO_ROOT/gpurun_out/${1:-cfg4_pmc}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 A="python3 $GRAFT_REPO_ROOT/bench.py --config 4 --cpu-seconds 0 --stream-chunks 9 --warmup 2"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel statistics of one bench leg: tools/r4_prof_leg.sh <tag> <bench args...>
+# kernel statistics of one bench leg: tools/prof_leg.sh <tag> <bench args...>
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out

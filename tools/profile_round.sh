@@ -10,10 +10,10 @@ mkdir -p $out
 cd $GRAFT_REPO_ROOT
 declare -A LEG=( [cfg1]="--legs main --two-streams 0 --wrappers 0" [cfg2]="--legs configs2" [f64]="--legs f64" )
 if [ "$what" != "pmc" ]; then
-  bash tools/r4_prof_leg.sh prof_$tag/cfg1 --legs main --steps 200 --warmup 20 --two-streams 0 --wrappers 0 > $out/cfg1.txt 2>&1; tail -9 $out/cfg1.txt
-  bash tools/r4_prof_leg.sh prof_$tag/cfg2 --legs configs2 --steps 10 --warmup 3 > $out/cfg2.txt 2>&1; tail -9 $out/cfg2.txt
-  bash tools/r4_prof_leg.sh prof_$tag/f64 --legs f64 --steps 20 --warmup 5 > $out/f64.txt 2>&1; tail -9 $out/f64.txt
-  bash tools/r4_prof_leg.sh prof_$tag/cfg4 --config 4 > $out/cfg4.txt 2>&1; tail -9 $out/cfg4.txt
+  bash tools/prof_leg.sh prof_$tag/cfg1 --legs main --steps 200 --warmup 20 --two-streams 0 --wrappers 0 > $out/cfg1.txt 2>&1; tail -9 $out/cfg1.txt
+  bash tools/prof_leg.sh prof_$tag/cfg2 --legs configs2 --steps 10 --warmup 3 > $out/cfg2.txt 2>&1; tail -9 $out/cfg2.txt
+  bash tools/prof_leg.sh prof_$tag/f64 --legs f64 --steps 20 --warmup 5 > $out/f64.txt 2>&1; tail -9 $out/f64.txt
+  bash tools/prof_leg.sh prof_$tag/cfg4 --config 4 > $out/cfg4.txt 2>&1; tail -9 $out/cfg4.txt
 fi
 if [ "$what" != "stats" ]; then
   for leg in cfg1 cfg2 f64; do
@@ -25,8 +25,8 @@ if [ "$what" != "stats" ]; then
     done
     python3 tools/traffic_summary.py $d > $out/${leg}_traffic_summary.txt 2>&1
   done
-  bash tools/r4_pmc_f64.sh prof_$tag/pmc_f64_sq > $out/pmc_f64_sq.log 2>&1; rm -rf $out/pmc_f64_sq/a $out/pmc_f64_sq/b
-  bash tools/r4_cfg4_pmc.sh prof_$tag/cfg4_pmc > $out/cfg4_pmc.log 2>&1; tail -3 $out/cfg4_pmc.log
+  bash tools/pmc_f64.sh prof_$tag/pmc_f64_sq > $out/pmc_f64_sq.log 2>&1; rm -rf $out/pmc_f64_sq/a $out/pmc_f64_sq/b
+  bash tools/cfg4_pmc.sh prof_$tag/cfg4_pmc > $out/cfg4_pmc.log 2>&1; tail -3 $out/cfg4_pmc.log
   python3 tools/make_traffic_json.py $out $tag > $out/traffic.json; cat $out/traffic.json
 fi
 du -sh $out
