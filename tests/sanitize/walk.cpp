@@ -4,7 +4,7 @@
 //   order 1 .. 12  x  record length 2^14 .. 2^22  x  float32 / float64  x  1 / 4 / 16 / 64 records
 // with the band tables the Python host code makes (gen_tables.py) and the scratch TfrPlan.workspace_for sizes for that batch:
 // plan build (band assignment, zoom classes, block item lists, split bands), qi_cwt_stx / qi_cwt / qi_stx with several output
-// sets (scratch carving, tiles, joint launches, launch geometry).  Checked on the way:
+// sets -- panels, bits, full and band-only reductions -- (scratch carving, tiles, joint launches, launch geometry).  Checked on the way:
 //   * every scratch region a run carves lies inside the workspace and no two live regions overlap (QI_LAYOUT_* hooks in
 //     qi_run.hip -> layout_note, qi_host_util.hip);
 //   * every table upload stays inside its allocation (AddressSanitizer on the malloc'ed "device" tables);
@@ -216,6 +216,14 @@ int main(int argc, char** argv) {
       if (qi_stx(p, sig, C, &bare, nullptr) != QI_OK) die("qi_stx (coefficients only)", c, C);
       if (qi_stx(p, sig, C, &full, nullptr) != QI_OK) die("qi_stx (coefficients, bits, reductions)", c, C);
       calls += 5;
+      {  // band powers and statistics without the per-time marginal (engine: reductions="band", the streaming pipeline's request)
+        qi_tfr_out b0 = lean0, b2 = lean2, bf = full;
+        b0.power_time = b2.power_time = bf.power_time = nullptr;
+        if (qi_cwt_stx(p, QI_BANK_STYX, sig, C, &b0, &b2, nullptr) != QI_OK) die("qi_cwt_stx (band-only reductions)", c, C);
+        if (qi_cwt(p, QI_BANK_STYX, sig, C, &bf, nullptr) != QI_OK) die("qi_cwt (coefficients, bits, band-only reductions)", c, C);
+        if (qi_stx(p, sig, C, &b2, nullptr) != QI_OK) die("qi_stx (band-only reductions)", c, C);
+        calls += 3;
+      }
       if (C == 4 && c.order == 3) {  // the atoms bank (cwt_atoms: circular kind) on a few shapes, then the plan's tables again
         if (qi_plan_set_gabor_bank(p, QI_BANK_ATOMS, c.B, c.p_re.data(), c.p_im.data(), c.omega.data(), c.amp.data(), nullptr) != QI_OK)
           die("qi_plan_set_gabor_bank (atoms)", c, C);

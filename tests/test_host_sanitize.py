@@ -28,7 +28,7 @@ def test_host_code_under_asan_ubsan_over_every_layout():
     assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-6000:]
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr and "LeakSanitizer" not in run.stderr
     rec = json.loads(run.stdout.strip().splitlines()[-1])
-    # 12 orders x 9 lengths x 2 precisions x 4 batch sizes, five transform calls each (+ the atoms bank on a few)
-    assert rec["ok"] and rec["plans"] == 864 and rec["calls"] >= 5 * 864 and rec["scratch_regions_checked"] > 40000
+    # 12 orders x 9 lengths x 2 precisions x 4 batch sizes, eight transform calls each (+ the atoms bank on a few)
+    assert rec["ok"] and rec["plans"] == 864 and rec["calls"] >= 8 * 864 and rec["scratch_regions_checked"] > 60000
     # (every table of these shapes is one for the native engines, but float64 at 2^14 samples: hipFFT engine by choice)
     assert rec["plans_on_native_engines"] == 864 - 12 * 4
